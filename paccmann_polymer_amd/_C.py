@@ -1,0 +1,86 @@
+"""ctypes binding of libppk.so (include/ppk.h).
+
+There is no CPU fallback: every product op goes through this library, and the
+import fails loudly when the library has not been built
+(`python -c "import __graft_entry__ as g; g.build()"` or
+`make -C paccmann_polymer_amd/csrc`).
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libppk.so')
+
+c_i64 = ctypes.c_int64
+c_int = ctypes.c_int
+c_sz = ctypes.c_size_t
+c_f32 = ctypes.c_float
+c_f64 = ctypes.c_double
+ptr = ctypes.c_void_p
+
+# name -> (restype, argtypes); mirrors include/ppk.h declaration by declaration.
+SIGNATURES = {
+    'ppk_version': (ctypes.c_char_p, []),
+    'ppk_last_error': (ctypes.c_char_p, []),
+    'ppk_device_count': (c_int, []),
+    'ppk_graphreg_dense_workspace_bytes': (c_sz, [c_i64, c_i64, c_i64]),
+    'ppk_graphreg_dense_fwd': (c_int, [ptr, c_i64, ptr, c_int, ptr, ptr,
+                                       c_i64, c_i64, c_i64, c_i64, c_i64,
+                                       ptr, ptr, ptr, c_sz, ptr]),
+    'ppk_graphreg_dense_bwd': (c_int, [ptr, c_i64, ptr, ptr,
+                                       c_i64, c_i64, c_i64, c_i64, c_i64,
+                                       ptr, ptr, c_i64, ptr, c_sz, ptr]),
+}
+
+
+class PPKError(RuntimeError):
+    pass
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f'{LIB_PATH} is missing: build the HIP library first '
+            '(make -C paccmann_polymer_amd/csrc). There is no CPU fallback.'
+        )
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)       # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    return lib
+
+
+lib = _load()
+
+_ERR_NAMES = {-1: 'shape', -2: 'alignment', -3: 'workspace', -4: 'unsupported', -5: 'hip', -6: 'null pointer'}
+
+
+def check(rc: int):
+    """0 -> ok.  Shape errors map to ValueError as in the reference
+    (graph_constrained_loss.py:42-43); everything else to PPKError."""
+    if rc == 0:
+        return
+    msg = lib.ppk_last_error().decode('utf-8', 'replace')
+    if rc == -1:
+        raise ValueError(msg)
+    raise PPKError(f'ppk error {rc} ({_ERR_NAMES.get(rc, "?")}): {msg}')
+
+
+def p(t):
+    """device pointer of a tensor (or None)."""
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def stream():
+    import torch
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def require_gpu(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise PPKError(
+                'paccmann_polymer_amd runs only on MI355X HIP tensors (got a CPU tensor); '
+                'there is no CPU fallback'
+            )

@@ -8,6 +8,11 @@ import fails loudly when the library has not been built
 import ctypes
 import os
 
+# torch must be imported BEFORE libppk.so is loaded: torch bundles its own HIP
+# runtime (torch/lib/libamdhip64.so) and both libraries must bind to that one
+# copy, otherwise device pointers and streams are not shared.
+import torch  # noqa: F401
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libppk.so')
 
@@ -73,7 +78,6 @@ def p(t):
 
 
 def stream():
-    import torch
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 

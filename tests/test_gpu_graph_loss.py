@@ -25,7 +25,9 @@ def rel(a, b):
 def run_gpu(z, G, sizes=None, g_kind='f64', up=1.0):
     import paccmann_polymer_amd as P
     zt = torch.tensor(z, device='cuda', requires_grad=True)
-    if g_kind == 'numpy':
+    if isinstance(G, list):
+        g = G
+    elif g_kind == 'numpy':
         g = np.asarray(G)
     elif g_kind == 'f32':
         g = torch.tensor(G, dtype=torch.float32)

@@ -76,6 +76,24 @@ int ppk_graphreg_dense_bwd(const float* z, int64_t ldz, const int64_t* seg_ptr, 
                            const float* dloss, float* dz, int64_t lddz,
                            void* workspace, size_t ws_bytes, ppk_stream_t stream);
 
+/* ---- fp32 MFMA GEMM ------------------------------------------------------
+ * C[M,N] = alpha * opA(A) . opB(B) + beta * C + bias[N]  (row-major, exact fp32
+ * v_mfma_f32_32x32x2_f32).  Replaces the dense contractions the reference
+ * reaches through torch.nn.GRU / nn.Linear inside paccmann_chemistry
+ * (call sites paccmann_polymer/models/paccmann_encoder.py:166-168) and
+ * `x @ weight` of torch_geometric GCNConv (reactions_infomax.py:66).
+ *   transA == 0: A is [M,K], lda >= K     transA != 0: A is [K,M], lda >= M
+ *   transB == 0: B is [K,N], ldb >= N     transB != 0: B is [N,K], ldb >= K
+ * A and B need 16-byte aligned bases and lda/ldb multiples of 4.  bias may be
+ * NULL.  The optional workspace (ppk_gemm_f32_workspace_bytes) enables the
+ * deterministic split-K path for small M x N with long K.
+ */
+size_t ppk_gemm_f32_workspace_bytes(int64_t M, int64_t N, int64_t K);
+int ppk_gemm_f32(int transA, int transB, int64_t M, int64_t N, int64_t K, float alpha,
+                 const float* A, int64_t lda, const float* B, int64_t ldb, float beta,
+                 float* C, int64_t ldc, const float* bias, void* workspace, size_t ws_bytes,
+                 ppk_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -35,6 +35,9 @@ SIGNATURES = {
     'ppk_graphreg_dense_bwd': (c_int, [ptr, c_i64, ptr, ptr,
                                        c_i64, c_i64, c_i64, c_i64, c_i64,
                                        ptr, ptr, c_i64, ptr, c_sz, ptr]),
+    'ppk_gemm_f32_workspace_bytes': (c_sz, [c_i64, c_i64, c_i64]),
+    'ppk_gemm_f32': (c_int, [c_int, c_int, c_i64, c_i64, c_i64, c_f32, ptr, c_i64, ptr, c_i64, c_f32,
+                             ptr, c_i64, ptr, ptr, c_sz, ptr]),
 }
 
 

@@ -1,0 +1,314 @@
+// fp32 MFMA GEMM for gfx950 (v_mfma_f32_32x32x2_f32: exact fp32, fmaf-chain numerics).
+//
+//   C[M,N] = alpha * opA(A) . opB(B) + beta * C + bias[N]        (row-major)
+//
+// Used for every dense contraction of the StackGRU VAE step (GRU gate GEMMs,
+// stack heads, mu/logvar heads, latent->hidden, logits, all weight gradients)
+// — the arithmetic that reaches cuDNN/MIOpen/ATen through torch.nn.GRU /
+// nn.Linear in the reference (paccmann_encoder.py:166-168 -> paccmann_chemistry).
+//
+// Structure: 256 threads = 4 waves in a 2x2 grid, block tile BM x BN x 32,
+// register-prefetched single LDS buffer (global loads of tile k+1 are in
+// flight while tile k is multiplied).  LDS images:
+//   k-contiguous operand  ->  [row][32 + 4]   read by ds_read_b128 (conflict-free: stride 36)
+//   x-contiguous operand  ->  [k][rows]       read by ds_read_b32  (32 consecutive dwords)
+// Per 8-deep K chunk lane (i, h = lane>>5) owns k = 4h..4h+3, so one 16-byte
+// read feeds four MFMA steps; A and B use the same k permutation.
+// Small grids with a long K are split along K into slabs that a second kernel
+// sums in slice order (bitwise reproducible, no atomics).
+#include "ppk_common.h"
+#include "ppk_kernels.h"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int BK = 32;
+constexpr int KC_STRIDE = BK + 4;   // floats
+
+// ---- global -> registers ---------------------------------------------------
+// k-contiguous source: element (row, k) at src[row * ld + k]
+template <int ROWS>
+__device__ __forceinline__ void gload_kc(f32x4 (&reg)[ROWS / 32], const float* __restrict__ src, long long ld,
+                                         int row0, int nrows, int k0, int kend, int tid)
+{
+#pragma unroll
+    for (int i = 0; i < ROWS / 32; ++i) {
+        const int idx = tid + 256 * i;
+        const int row = idx >> 3, kq = (idx & 7) << 2;
+        const int gr = row0 + row, gk = k0 + kq;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (gr < nrows) {
+            const float* p = src + (long long)gr * ld + gk;
+            if (gk + 3 < kend) {
+                v = *reinterpret_cast<const f32x4*>(p);
+            } else {
+                if (gk < kend) v.x = p[0];
+                if (gk + 1 < kend) v.y = p[1];
+                if (gk + 2 < kend) v.z = p[2];
+            }
+        }
+        reg[i] = v;
+    }
+}
+// x-contiguous source: element (x, k) at src[k * ld + x]
+template <int ROWS>
+__device__ __forceinline__ void gload_xc(f32x4 (&reg)[ROWS / 32], const float* __restrict__ src, long long ld,
+                                         int x0, int nx, int k0, int kend, int tid)
+{
+    constexpr int QPR = ROWS / 4;   // float4 per k-row
+#pragma unroll
+    for (int i = 0; i < ROWS / 32; ++i) {
+        const int idx = tid + 256 * i;
+        const int k = idx / QPR, xq = (idx % QPR) << 2;
+        const int gk = k0 + k, gx = x0 + xq;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (gk < kend) {
+            const float* p = src + (long long)gk * ld + gx;
+            if (gx + 3 < nx) {
+                v = *reinterpret_cast<const f32x4*>(p);
+            } else {
+                if (gx < nx) v.x = p[0];
+                if (gx + 1 < nx) v.y = p[1];
+                if (gx + 2 < nx) v.z = p[2];
+            }
+        }
+        reg[i] = v;
+    }
+}
+// ---- registers -> LDS --------------------------------------------------------
+template <int ROWS>
+__device__ __forceinline__ void sstore_kc(float* lds, const f32x4 (&reg)[ROWS / 32], int tid)
+{
+#pragma unroll
+    for (int i = 0; i < ROWS / 32; ++i) {
+        const int idx = tid + 256 * i;
+        const int row = idx >> 3, kq = (idx & 7) << 2;
+        *reinterpret_cast<f32x4*>(lds + row * KC_STRIDE + kq) = reg[i];
+    }
+}
+template <int ROWS>
+__device__ __forceinline__ void sstore_xc(float* lds, const f32x4 (&reg)[ROWS / 32], int tid)
+{
+    constexpr int QPR = ROWS / 4;
+#pragma unroll
+    for (int i = 0; i < ROWS / 32; ++i) {
+        const int idx = tid + 256 * i;
+        const int k = idx / QPR, xq = (idx % QPR) << 2;
+        *reinterpret_cast<f32x4*>(lds + k * ROWS + xq) = reg[i];
+    }
+}
+// ---- LDS -> MFMA fragment (4 k-steps of one 32-row tile) ---------------------
+template <int ROWS, bool KC>
+__device__ __forceinline__ f32x4 frag(const float* lds, int row, int chunk, int h)
+{
+    if constexpr (KC) {
+        return *reinterpret_cast<const f32x4*>(lds + row * KC_STRIDE + chunk * 8 + 4 * h);
+    } else {
+        const float* p = lds + (chunk * 8 + 4 * h) * ROWS + row;
+        f32x4 v = {p[0], p[ROWS], p[2 * ROWS], p[3 * ROWS]};
+        return v;
+    }
+}
+
+template <int ROWS, bool KC>
+constexpr int lds_floats() { return KC ? ROWS * KC_STRIDE : BK * ROWS; }
+
+struct GemmArgs {
+    const float* A; const float* B; float* C; const float* bias;
+    long long lda, ldb, ldc;
+    int M, N, K;
+    float alpha, beta;
+    int ksplit;          // number of K slices (grid.z)
+    int kslice;          // K elements per slice (multiple of BK)
+    float* slabs;        // [ksplit][M][N] when ksplit > 1
+};
+
+template <int BM, int BN, bool A_KC, bool B_KC>
+__global__ __launch_bounds__(256) void k_gemm(const GemmArgs g)
+{
+    constexpr int TM = BM / 64, TN = BN / 64;       // 32x32 tiles per wave
+    __shared__ __align__(16) float lds[lds_floats<BM, A_KC>() + lds_floats<BN, B_KC>()];
+    float* ldsA = lds;
+    float* ldsB = lds + lds_floats<BM, A_KC>();
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int li = lane & 31, h = lane >> 5;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const int kbeg = blockIdx.z * g.kslice;
+    const int kend = min(g.K, kbeg + g.kslice);
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    f32x4 ra[BM / 32], rb[BN / 32];
+    auto gload = [&](int k0) {
+        if constexpr (A_KC) gload_kc<BM>(ra, g.A, g.lda, m0, g.M, k0, kend, tid);
+        else                gload_xc<BM>(ra, g.A, g.lda, m0, g.M, k0, kend, tid);
+        if constexpr (B_KC) gload_kc<BN>(rb, g.B, g.ldb, n0, g.N, k0, kend, tid);
+        else                gload_xc<BN>(rb, g.B, g.ldb, n0, g.N, k0, kend, tid);
+    };
+    gload(kbeg);
+    for (int k0 = kbeg; k0 < kend; k0 += BK) {
+        if constexpr (A_KC) sstore_kc<BM>(ldsA, ra, tid); else sstore_xc<BM>(ldsA, ra, tid);
+        if constexpr (B_KC) sstore_kc<BN>(ldsB, rb, tid); else sstore_xc<BN>(ldsB, rb, tid);
+        __syncthreads();
+        if (k0 + BK < kend) gload(k0 + BK);
+#pragma unroll
+        for (int c = 0; c < BK / 8; ++c) {
+            f32x4 a[TM], b[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) a[i] = frag<BM, A_KC>(ldsA, wm * (BM / 2) + i * 32 + li, c, h);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) b[j] = frag<BN, B_KC>(ldsB, wn * (BN / 2) + j * 32 + li, c, h);
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][s], b[j][s], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+
+    // epilogue.  C/D map of the 32x32 tile: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
+    const bool slab = g.ksplit > 1;
+    float* Cout = slab ? g.slabs + (long long)blockIdx.z * g.M * g.N : g.C;
+    const long long ldo = slab ? g.N : g.ldc;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int col = n0 + wn * (BN / 2) + j * 32 + li;
+            if (col >= g.N) continue;
+            const float bv = (!slab && g.bias) ? g.bias[col] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wm * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (row >= g.M) continue;
+                float* p = Cout + (long long)row * ldo + col;
+                float v = acc[i][j][r];
+                if (!slab) {
+                    v = g.alpha * v + bv;
+                    if (g.beta != 0.f) v = fmaf(g.beta, *p, v);
+                }
+                *p = v;
+            }
+        }
+}
+
+// sums the K slabs in slice order, then applies alpha / beta / bias.
+__global__ __launch_bounds__(256) void k_gemm_reduce(const GemmArgs g)
+{
+    const long long total = (long long)g.M * g.N;
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+        float s = 0.f;
+        for (int z = 0; z < g.ksplit; ++z) s += g.slabs[(long long)z * total + e];
+        const int row = (int)(e / g.N), col = (int)(e % g.N);
+        float* p = g.C + (long long)row * g.ldc + col;
+        float v = g.alpha * s + (g.bias ? g.bias[col] : 0.f);
+        if (g.beta != 0.f) v = fmaf(g.beta, *p, v);
+        *p = v;
+    }
+}
+
+template <int BM, int BN>
+void launch(const GemmArgs& g, bool a_kc, bool b_kc, hipStream_t stream)
+{
+    dim3 grid((g.N + BN - 1) / BN, (g.M + BM - 1) / BM, g.ksplit), block(256);
+    if (a_kc && b_kc)        k_gemm<BM, BN, true, true><<<grid, block, 0, stream>>>(g);
+    else if (a_kc && !b_kc)  k_gemm<BM, BN, true, false><<<grid, block, 0, stream>>>(g);
+    else if (!a_kc && b_kc)  k_gemm<BM, BN, false, true><<<grid, block, 0, stream>>>(g);
+    else                     k_gemm<BM, BN, false, false><<<grid, block, 0, stream>>>(g);
+}
+
+inline long long cdiv(long long a, long long b) { return (a + b - 1) / b; }
+
+}  // namespace
+
+namespace ppk {
+
+size_t gemm_workspace_bytes(int64_t M, int64_t N, int64_t K)
+{
+    // room for up to 16 K-slabs
+    (void)K;
+    return ppk_align_up(sizeof(float) * (size_t)M * (size_t)N * 16, 256);
+}
+
+int gemm(int transA, int transB, int64_t M, int64_t N, int64_t K, float alpha,
+         const float* A, int64_t lda, const float* B, int64_t ldb, float beta,
+         float* C, int64_t ldc, const float* bias, void* ws, size_t ws_bytes, hipStream_t stream)
+{
+    if (M < 0 || N < 0 || K < 0) PPK_FAIL(PPK_ERR_SHAPE, "gemm: negative size");
+    if (M == 0 || N == 0) return PPK_OK;
+    if (!A || !B || !C) PPK_FAIL(PPK_ERR_NULL, "gemm: null operand");
+    if (M > 0x7fffffff || N > 0x7fffffff || K > 0x7fffffff) PPK_FAIL(PPK_ERR_UNSUP, "gemm: dimension >= 2^31");
+    const bool a_kc = !transA, b_kc = transB != 0;
+    if (lda < (a_kc ? K : M) || ldb < (b_kc ? K : N) || ldc < N)
+        PPK_FAIL(PPK_ERR_SHAPE, "gemm: leading dimension too small (lda=%lld ldb=%lld ldc=%lld)", (long long)lda, (long long)ldb, (long long)ldc);
+    if ((lda & 3) || (ldb & 3) || ((uintptr_t)A & 15) || ((uintptr_t)B & 15))
+        PPK_FAIL(PPK_ERR_ALIGN, "gemm: A/B need 16-byte aligned bases and leading dimensions that are multiples of 4");
+
+    GemmArgs g;
+    g.A = A; g.B = B; g.C = C; g.bias = bias;
+    g.lda = lda; g.ldb = ldb; g.ldc = ldc;
+    g.M = (int)M; g.N = (int)N; g.K = (int)K;
+    g.alpha = alpha; g.beta = beta;
+    g.ksplit = 1; g.kslice = (int)(cdiv(K > 0 ? K : 1, BK) * BK); g.slabs = nullptr;
+
+    // tile choice: 128x128 when it fills the chip, else 64x64
+    const long long big = cdiv(M, 128) * cdiv(N, 128), small = cdiv(M, 64) * cdiv(N, 64);
+    const bool use_big = big >= 200;
+    const long long blocks = use_big ? big : small;
+    if (blocks < 128 && K >= 2048 && ws) {
+        long long want = 512 / blocks;                       // aim at ~2 blocks per CU
+        long long maxs = K / 512;                            // keep >= 512 of K per slice
+        long long s = want < maxs ? want : maxs;
+        if (s > 16) s = 16;
+        const size_t need = sizeof(float) * (size_t)M * (size_t)N * (size_t)(s > 1 ? s : 0);
+        if (s > 1 && need <= ws_bytes) {
+            g.ksplit = (int)s;
+            g.kslice = (int)(cdiv(cdiv(K, s), BK) * BK);
+            g.ksplit = (int)cdiv(K, g.kslice);
+            g.slabs = (float*)ws;
+        }
+    }
+    if (use_big) launch<128, 128>(g, a_kc, b_kc, stream);
+    else         launch<64, 64>(g, a_kc, b_kc, stream);
+    PPK_CHECK_LAUNCH("k_gemm");
+    if (g.ksplit > 1) {
+        long long total = (long long)M * N;
+        unsigned nb = (unsigned)(cdiv(total, 256) < 2048 ? cdiv(total, 256) : 2048);
+        k_gemm_reduce<<<dim3(nb), dim3(256), 0, stream>>>(g);
+        PPK_CHECK_LAUNCH("k_gemm_reduce");
+    }
+    return PPK_OK;
+}
+
+}  // namespace ppk
+
+extern "C" {
+
+size_t ppk_gemm_f32_workspace_bytes(int64_t M, int64_t N, int64_t K)
+{
+    if (M <= 0 || N <= 0) return 0;
+    return ppk::gemm_workspace_bytes(M, N, K);
+}
+
+int ppk_gemm_f32(int transA, int transB, int64_t M, int64_t N, int64_t K, float alpha,
+                 const float* A, int64_t lda, const float* B, int64_t ldb, float beta,
+                 float* C, int64_t ldc, const float* bias, void* workspace, size_t ws_bytes,
+                 hipStream_t stream)
+{
+    return ppk::gemm(transA, transB, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, bias, workspace, ws_bytes, stream);
+}
+
+}  // extern "C"

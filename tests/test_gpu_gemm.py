@@ -1,0 +1,70 @@
+"""ppk_gemm_f32 (fp32 MFMA) against torch fp64 matmul; tolerance 2e-6 rel
+(fp32 fmaf-chain accumulation)."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+SHAPES = [
+    # M, N, K
+    (128, 128, 32), (64, 64, 8), (1, 1, 1), (37, 53, 178), (2048, 1536, 512), (300, 1536, 178),
+    (2048, 53, 512), (77, 690, 1536), (1536, 512, 5000), (53, 512, 3001), (130, 200, 4),
+]
+
+
+@pytest.mark.parametrize('M,N,K', SHAPES)
+@pytest.mark.parametrize('tA,tB', [(0, 1), (0, 0), (1, 0), (1, 1)])
+def test_gemm_layouts(M, N, K, tA, tB):
+    from paccmann_polymer_amd import ops
+    torch.manual_seed(M * 7 + N * 3 + K)
+    lda = ((M if tA else K) + 3) // 4 * 4 + 4
+    ldb = ((K if tB else N) + 3) // 4 * 4
+    Afull = torch.randn(K if tA else M, lda, device='cuda')
+    Bfull = torch.randn(N if tB else K, ldb, device='cuda')
+    A = Afull[:, :(M if tA else K)]
+    B = Bfull[:, :(K if tB else N)]
+    bias = torch.randn(N, device='cuda')
+    C0 = torch.randn(M, N, device='cuda')
+    ws = torch.empty(ops._C.lib.ppk_gemm_f32_workspace_bytes(M, N, K), dtype=torch.uint8, device='cuda')
+    C = C0.clone()
+    ops.gemm(A, B, bool(tA), bool(tB), alpha=0.5, beta=2.0, C=C, bias=bias, ws=ws)
+    opA = (A.T if tA else A).double()
+    opB = (B.T if tB else B).double()
+    ref = 0.5 * (opA @ opB) + 2.0 * C0.double() + bias.double()
+    scale = (opA.abs() @ opB.abs()).max().item() + 1.0
+    assert (C.double() - ref).abs().max().item() <= 2e-6 * scale
+    # no bias / beta = 0 must not read C (NaN-poisoned)
+    C2 = torch.full((M, N), float('nan'), device='cuda')
+    ops.gemm(A, B, bool(tA), bool(tB), C=C2, beta=0.0, ws=ws)
+    assert (C2.double() - opA @ opB).abs().max().item() <= 2e-6 * scale
+
+
+def test_gemm_asymmetric_identity():
+    # A = I with an asymmetric B catches a transposed C write
+    from paccmann_polymer_amd import ops
+    n = 96
+    A = torch.eye(n, device='cuda')
+    B = torch.arange(n * n, device='cuda', dtype=torch.float32).reshape(n, n)
+    assert torch.equal(ops.gemm(A, B), B)
+    assert torch.equal(ops.gemm(A, B, transB=True), B.T)
+
+
+def test_gemm_reproducible_splitk():
+    from paccmann_polymer_amd import ops
+    torch.manual_seed(0)
+    A = torch.randn(20000, 256, device='cuda')
+    B = torch.randn(20000, 128, device='cuda')
+    ws = torch.empty(ops._C.lib.ppk_gemm_f32_workspace_bytes(256, 128, 20000), dtype=torch.uint8, device='cuda')
+    c1 = ops.gemm(A, B, transA=True, ws=ws)
+    c2 = ops.gemm(A, B, transA=True, ws=ws)
+    assert torch.equal(c1, c2)
+    ref = A.double().T @ B.double()
+    assert (c1.double() - ref).abs().max().item() <= 1e-5 * ref.abs().max().item()
+
+
+def test_gemm_errors():
+    from paccmann_polymer_amd import ops
+    A = torch.zeros(8, 6, device='cuda')   # lda = 6: not a multiple of 4
+    B = torch.zeros(6, 8, device='cuda')
+    with pytest.raises(ops._C.PPKError):
+        ops.gemm(A, B)

@@ -84,8 +84,8 @@ int ppk_graphreg_dense_bwd(const float* z, int64_t ldz, const int64_t* seg_ptr, 
  * `x @ weight` of torch_geometric GCNConv (reactions_infomax.py:66).
  *   transA == 0: A is [M,K], lda >= K     transA != 0: A is [K,M], lda >= M
  *   transB == 0: B is [K,N], ldb >= N     transB != 0: B is [N,K], ldb >= K
- * A and B need 16-byte aligned bases and lda/ldb multiples of 4.  bias may be
- * NULL.  The optional workspace (ppk_gemm_f32_workspace_bytes) enables the
+ * 16-byte aligned bases with lda/ldb multiples of 4 take the float4 load path
+ * (anything else falls back to scalar loads).  bias may be NULL.  The optional workspace (ppk_gemm_f32_workspace_bytes) enables the
  * deterministic split-K path for small M x N with long K.
  */
 size_t ppk_gemm_f32_workspace_bytes(int64_t M, int64_t N, int64_t K);
@@ -93,6 +93,79 @@ int ppk_gemm_f32(int transA, int transB, int64_t M, int64_t N, int64_t K, float 
                  const float* A, int64_t lda, const float* B, int64_t ldb, float beta,
                  float* C, int64_t ldc, const float* bias, void* workspace, size_t ws_bytes,
                  ppk_stream_t stream);
+
+/* ---- K1: stack-augmented GRU sequence (packed, length-sorted batch) -------
+ * Replaces the per-timestep loop of paccmann_chemistry StackGRU / nn.GRU that
+ * the reference drives from paccmann_polymer/models/paccmann_encoder.py:166
+ * (TeacherVAE.encode) and :168 (TeacherVAE.decode); semantics SURVEY.md
+ * Appendix B.  batch_sizes_host is a HOST array [T] (PackedSequence.batch_sizes);
+ * w_ih / w_hh / b_ih / b_hh are HOST arrays of L device pointers
+ * (nn.GRU weight_ih_l{k} [3H, I_k], weight_hh_l{k} [3H, H], gate order r|z|n);
+ * ld_wih0 is the row stride of w_ih[0] (>= E + W); wcs [3+W, H] / bcs [3+W] are
+ * stack_controls_layer rows 0..2 followed by stack_input_layer; h0 [L, B, H].
+ * Saved activations (caller-allocated, consumed by the backward):
+ *   X [NT, ldx], Hs / HP [L, NT, H], gates [L, NT, 4H], S [NT, D, W], CS [NT, ldcs].
+ */
+size_t ppk_stackgru_seq_fwd_workspace_bytes(int64_t B, int64_t H, int64_t W);
+int ppk_stackgru_seq_fwd(int64_t T, const int64_t* batch_sizes_host, int64_t B, int64_t NT,
+                         int64_t V, int64_t E, int64_t H, int64_t L, int64_t W, int64_t D,
+                         const int64_t* tokens, const float* emb,
+                         const float* const* w_ih, int64_t ld_wih0, const float* const* w_hh,
+                         const float* const* b_ih, const float* const* b_hh,
+                         const float* wcs, const float* bcs, const float* h0,
+                         float* X, int64_t ldx, float* Hs, float* HP, float* gates, float* S,
+                         float* CS, int64_t ldcs, void* workspace, size_t ws_bytes, ppk_stream_t stream);
+/* dHtop [NT, H] = gradient at the top layer's output of every step.  Outputs:
+ * dX [NT, ldx], DGI / DGH [L, NT, 3H] (gate pre-activation gradients of the
+ * input / hidden side), DCS [NT, ldcs], dh0 [L, B, H].  Weight gradients are
+ * single GEMMs over these: dW_ih = DGI^T In, dW_hh = DGH^T HP, dWcs = DCS^T HP[L-1]. */
+size_t ppk_stackgru_seq_bwd_workspace_bytes(int64_t B, int64_t H, int64_t W, int64_t D);
+int ppk_stackgru_seq_bwd(int64_t T, const int64_t* batch_sizes_host, int64_t B, int64_t NT,
+                         int64_t V, int64_t E, int64_t H, int64_t L, int64_t W, int64_t D,
+                         const float* const* w_ih, int64_t ld_wih0, const float* const* w_hh, const float* wcs,
+                         const float* HP, const float* gates, const float* S, const float* CS, int64_t ldcs,
+                         const float* dHtop, float* dX, int64_t ldx, float* DGI, float* DGH, float* DCS,
+                         float* dh0, void* workspace, size_t ws_bytes, ppk_stream_t stream);
+
+/* ---- row gather / scatter, column sums, embedding gradient ----------------
+ * (index_select / index_put / sum(0) / nn.Embedding backward in the reference's
+ * torch graph.)  All deterministic. */
+int ppk_gather_rows(const float* src, int64_t ld_src, int64_t src_rows, const int64_t* idx, int64_t n_rows, int64_t width,
+                    float* dst, int64_t ld_dst, ppk_stream_t stream);
+int ppk_scatter_rows(const float* src, int64_t ld_src, const int64_t* idx, int64_t n_rows, int64_t width,
+                     float* dst, int64_t ld_dst, int64_t dst_rows, ppk_stream_t stream);
+size_t ppk_colsum_workspace_bytes(int64_t rows, int64_t cols);
+int ppk_colsum(const float* A, int64_t lda, int64_t rows, int64_t cols, float beta, float* out,
+               void* workspace, size_t ws_bytes, ppk_stream_t stream);
+size_t ppk_embedding_bwd_workspace_bytes(int64_t NT, int64_t V, int64_t E);
+int ppk_embedding_bwd(const float* dX, int64_t ldx, const int64_t* tokens, int64_t NT, int64_t V, int64_t E,
+                      int64_t padding_idx, float* dEmb, void* workspace, size_t ws_bytes, ppk_stream_t stream);
+
+/* ---- K2: cross-entropy over packed logits ---------------------------------
+ * nn.CrossEntropyLoss(ignore_index=0) of TeacherVAE.decode (paccmann_encoder.py:168):
+ * mean over rows whose target != ignore_index.  The workspace carries the
+ * per-row logsumexp and the valid count from fwd to bwd. */
+size_t ppk_ce_workspace_bytes(int64_t rows);
+int ppk_ce_fwd(const float* logits, int64_t ldl, const int64_t* targets, int64_t rows, int64_t V, int64_t ignore_index,
+               float* loss, void* workspace, size_t ws_bytes, ppk_stream_t stream);
+int ppk_ce_bwd(const float* logits, int64_t ldl, const int64_t* targets, int64_t rows, int64_t V, int64_t ignore_index,
+               const float* dloss, float* dlogits, int64_t ldd, const void* workspace, size_t ws_bytes, ppk_stream_t stream);
+
+/* ---- K3: reparameterise + KL ------------------------------------------------
+ * TeacherVAE.reparameterize (paccmann_encoder.py:167; in-tree twin
+ * experiments/cora/vae.py:31-34) with injected eps, fused with the KL term
+ * -0.5 sum(1 + logvar - mu^2 - exp(logvar)) (cora/vae.py:50).  kl / dz / dkl may be NULL. */
+size_t ppk_reparam_workspace_bytes(int64_t n);
+int ppk_reparam_fwd(const float* mu, const float* logvar, const float* eps, int64_t n, float* z, float* kl,
+                    void* workspace, size_t ws_bytes, ppk_stream_t stream);
+int ppk_reparam_bwd(const float* mu, const float* logvar, const float* eps, int64_t n, const float* dz, const float* dkl,
+                    float* dmu, float* dlogvar, ppk_stream_t stream);
+
+/* ---- flat Adam --------------------------------------------------------------
+ * optimizer.step() of reactions_vae.py:96 (OPTIMIZER_FACTORY['adam'] = torch.optim.Adam)
+ * over one flat fp32 parameter buffer; step is 1-based. */
+int ppk_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
+                  float lr, float beta1, float beta2, float eps, float weight_decay, int64_t step, ppk_stream_t stream);
 
 #ifdef __cplusplus
 }

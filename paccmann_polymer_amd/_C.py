@@ -38,6 +38,27 @@ SIGNATURES = {
     'ppk_gemm_f32_workspace_bytes': (c_sz, [c_i64, c_i64, c_i64]),
     'ppk_gemm_f32': (c_int, [c_int, c_int, c_i64, c_i64, c_i64, c_f32, ptr, c_i64, ptr, c_i64, c_f32,
                              ptr, c_i64, ptr, ptr, c_sz, ptr]),
+    'ppk_stackgru_seq_fwd_workspace_bytes': (c_sz, [c_i64, c_i64, c_i64]),
+    'ppk_stackgru_seq_fwd': (c_int, [c_i64, ptr, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64,
+                                     ptr, ptr, ptr, c_i64, ptr, ptr, ptr, ptr, ptr, ptr,
+                                     ptr, c_i64, ptr, ptr, ptr, ptr, ptr, c_i64, ptr, c_sz, ptr]),
+    'ppk_stackgru_seq_bwd_workspace_bytes': (c_sz, [c_i64, c_i64, c_i64, c_i64]),
+    'ppk_stackgru_seq_bwd': (c_int, [c_i64, ptr, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64,
+                                     ptr, c_i64, ptr, ptr, ptr, ptr, ptr, ptr, c_i64,
+                                     ptr, ptr, c_i64, ptr, ptr, ptr, ptr, ptr, c_sz, ptr]),
+    'ppk_gather_rows': (c_int, [ptr, c_i64, c_i64, ptr, c_i64, c_i64, ptr, c_i64, ptr]),
+    'ppk_scatter_rows': (c_int, [ptr, c_i64, ptr, c_i64, c_i64, ptr, c_i64, c_i64, ptr]),
+    'ppk_colsum_workspace_bytes': (c_sz, [c_i64, c_i64]),
+    'ppk_colsum': (c_int, [ptr, c_i64, c_i64, c_i64, c_f32, ptr, ptr, c_sz, ptr]),
+    'ppk_embedding_bwd_workspace_bytes': (c_sz, [c_i64, c_i64, c_i64]),
+    'ppk_embedding_bwd': (c_int, [ptr, c_i64, ptr, c_i64, c_i64, c_i64, c_i64, ptr, ptr, c_sz, ptr]),
+    'ppk_ce_workspace_bytes': (c_sz, [c_i64]),
+    'ppk_ce_fwd': (c_int, [ptr, c_i64, ptr, c_i64, c_i64, c_i64, ptr, ptr, c_sz, ptr]),
+    'ppk_ce_bwd': (c_int, [ptr, c_i64, ptr, c_i64, c_i64, c_i64, ptr, ptr, c_i64, ptr, c_sz, ptr]),
+    'ppk_reparam_workspace_bytes': (c_sz, [c_i64]),
+    'ppk_reparam_fwd': (c_int, [ptr, ptr, ptr, c_i64, ptr, ptr, ptr, c_sz, ptr]),
+    'ppk_reparam_bwd': (c_int, [ptr, ptr, ptr, c_i64, ptr, ptr, ptr, ptr, ptr]),
+    'ppk_adam_step': (c_int, [ptr, ptr, ptr, ptr, c_i64, c_f32, c_f32, c_f32, c_f32, c_f32, c_i64, ptr]),
 }
 
 

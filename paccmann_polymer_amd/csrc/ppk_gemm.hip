@@ -31,7 +31,7 @@ constexpr int KC_STRIDE = BK + 4;   // floats
 // k-contiguous source: element (row, k) at src[row * ld + k]
 template <int ROWS>
 __device__ __forceinline__ void gload_kc(f32x4 (&reg)[ROWS / 32], const float* __restrict__ src, long long ld,
-                                         int row0, int nrows, int k0, int kend, int tid)
+                                         int row0, int nrows, int k0, int kend, int tid, bool vec)
 {
 #pragma unroll
     for (int i = 0; i < ROWS / 32; ++i) {
@@ -41,12 +41,13 @@ __device__ __forceinline__ void gload_kc(f32x4 (&reg)[ROWS / 32], const float* _
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
         if (gr < nrows) {
             const float* p = src + (long long)gr * ld + gk;
-            if (gk + 3 < kend) {
+            if (vec && gk + 3 < kend) {
                 v = *reinterpret_cast<const f32x4*>(p);
             } else {
                 if (gk < kend) v.x = p[0];
                 if (gk + 1 < kend) v.y = p[1];
                 if (gk + 2 < kend) v.z = p[2];
+                if (gk + 3 < kend) v.w = p[3];
             }
         }
         reg[i] = v;
@@ -55,7 +56,7 @@ __device__ __forceinline__ void gload_kc(f32x4 (&reg)[ROWS / 32], const float* _
 // x-contiguous source: element (x, k) at src[k * ld + x]
 template <int ROWS>
 __device__ __forceinline__ void gload_xc(f32x4 (&reg)[ROWS / 32], const float* __restrict__ src, long long ld,
-                                         int x0, int nx, int k0, int kend, int tid)
+                                         int x0, int nx, int k0, int kend, int tid, bool vec)
 {
     constexpr int QPR = ROWS / 4;   // float4 per k-row
 #pragma unroll
@@ -66,12 +67,13 @@ __device__ __forceinline__ void gload_xc(f32x4 (&reg)[ROWS / 32], const float* _
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
         if (gk < kend) {
             const float* p = src + (long long)gk * ld + gx;
-            if (gx + 3 < nx) {
+            if (vec && gx + 3 < nx) {
                 v = *reinterpret_cast<const f32x4*>(p);
             } else {
                 if (gx < nx) v.x = p[0];
                 if (gx + 1 < nx) v.y = p[1];
                 if (gx + 2 < nx) v.z = p[2];
+                if (gx + 3 < nx) v.w = p[3];
             }
         }
         reg[i] = v;
@@ -123,6 +125,7 @@ struct GemmArgs {
     int ksplit;          // number of K slices (grid.z)
     int kslice;          // K elements per slice (multiple of BK)
     float* slabs;        // [ksplit][M][N] when ksplit > 1
+    int a_vec, b_vec;    // operand base 16-B aligned and leading dimension % 4 == 0 -> float4 loads
 };
 
 template <int BM, int BN, bool A_KC, bool B_KC>
@@ -150,10 +153,10 @@ __global__ __launch_bounds__(256) void k_gemm(const GemmArgs g)
 
     f32x4 ra[BM / 32], rb[BN / 32];
     auto gload = [&](int k0) {
-        if constexpr (A_KC) gload_kc<BM>(ra, g.A, g.lda, m0, g.M, k0, kend, tid);
-        else                gload_xc<BM>(ra, g.A, g.lda, m0, g.M, k0, kend, tid);
-        if constexpr (B_KC) gload_kc<BN>(rb, g.B, g.ldb, n0, g.N, k0, kend, tid);
-        else                gload_xc<BN>(rb, g.B, g.ldb, n0, g.N, k0, kend, tid);
+        if constexpr (A_KC) gload_kc<BM>(ra, g.A, g.lda, m0, g.M, k0, kend, tid, g.a_vec);
+        else                gload_xc<BM>(ra, g.A, g.lda, m0, g.M, k0, kend, tid, g.a_vec);
+        if constexpr (B_KC) gload_kc<BN>(rb, g.B, g.ldb, n0, g.N, k0, kend, tid, g.b_vec);
+        else                gload_xc<BN>(rb, g.B, g.ldb, n0, g.N, k0, kend, tid, g.b_vec);
     };
     gload(kbeg);
     for (int k0 = kbeg; k0 < kend; k0 += BK) {
@@ -254,14 +257,16 @@ int gemm(int transA, int transB, int64_t M, int64_t N, int64_t K, float alpha,
     const bool a_kc = !transA, b_kc = transB != 0;
     if (lda < (a_kc ? K : M) || ldb < (b_kc ? K : N) || ldc < N)
         PPK_FAIL(PPK_ERR_SHAPE, "gemm: leading dimension too small (lda=%lld ldb=%lld ldc=%lld)", (long long)lda, (long long)ldb, (long long)ldc);
-    if ((lda & 3) || (ldb & 3) || ((uintptr_t)A & 15) || ((uintptr_t)B & 15))
-        PPK_FAIL(PPK_ERR_ALIGN, "gemm: A/B need 16-byte aligned bases and leading dimensions that are multiples of 4");
+    if (((uintptr_t)A & 3) || ((uintptr_t)B & 3) || ((uintptr_t)C & 3))
+        PPK_FAIL(PPK_ERR_ALIGN, "gemm: operands must be 4-byte aligned");
 
     GemmArgs g;
     g.A = A; g.B = B; g.C = C; g.bias = bias;
     g.lda = lda; g.ldb = ldb; g.ldc = ldc;
     g.M = (int)M; g.N = (int)N; g.K = (int)K;
     g.alpha = alpha; g.beta = beta;
+    g.a_vec = !(lda & 3) && !((uintptr_t)A & 15);
+    g.b_vec = !(ldb & 3) && !((uintptr_t)B & 15);
     g.ksplit = 1; g.kslice = (int)(cdiv(K > 0 ? K : 1, BK) * BK); g.slabs = nullptr;
 
     // tile choice: 128x128 when it fills the chip, else 64x64

@@ -1,0 +1,381 @@
+// Small fused kernels around the GRU core: row gather / scatter, deterministic
+// column sums, embedding gradient, logits cross-entropy (K2), reparameterise +
+// KL (K3), flat Adam.  Every reduction has a fixed order (no float atomics).
+#include "ppk_common.h"
+
+namespace {
+
+inline unsigned grid_for(long long work, unsigned cap = 4096)
+{
+    long long b = (work + 255) / 256;
+    if (b < 1) b = 1;
+    return (unsigned)(b < cap ? b : cap);
+}
+
+// dst[i, :] = src[idx[i], :]   (gather)      or   dst[idx[i], :] = src[i, :]   (scatter, distinct idx)
+template <bool SCATTER>
+__global__ __launch_bounds__(256) void k_rows(const float* __restrict__ src, long long lds_, const int64_t* __restrict__ idx,
+                                              long long n_rows, int width, long long src_rows, float* __restrict__ dst, long long ldd,
+                                              long long dst_rows)
+{
+    const long long total = n_rows * width;
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+        const long long i = e / width;
+        const int c = (int)(e % width);
+        const long long j = idx[i];
+        if (SCATTER) {
+            if (j >= 0 && j < dst_rows) dst[j * ldd + c] = src[i * lds_ + c];
+        } else {
+            dst[i * ldd + c] = (j >= 0 && j < src_rows) ? src[j * lds_ + c] : 0.0f;
+        }
+    }
+}
+
+// ---- column sums: out[c] = sum_r A[r, c] ; two passes, fixed order ----------
+constexpr int CS_CHUNK = 512;   // rows per partial
+__global__ __launch_bounds__(256) void k_colsum_part(const float* __restrict__ A, long long lda, long long R, int C,
+                                                     float* __restrict__ part)
+{
+    const long long r0 = (long long)blockIdx.y * CS_CHUNK;
+    const long long r1 = r0 + CS_CHUNK < R ? r0 + CS_CHUNK : R;
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    float acc = 0.f;
+    for (long long r = r0; r < r1; ++r) acc += A[r * lda + c];
+    part[(long long)blockIdx.y * C + c] = acc;
+}
+__global__ __launch_bounds__(256) void k_colsum_final(const float* __restrict__ part, int nparts, int C, float beta,
+                                                      float* __restrict__ out)
+{
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    double acc = 0.0;
+    for (int p = 0; p < nparts; ++p) acc += (double)part[(long long)p * C + c];
+    out[c] = (beta != 0.f ? beta * out[c] : 0.f) + (float)acc;
+}
+
+// ---- embedding gradient: dEmb[v, :] = sum_{rows with tok == v} dX[row, 0:E] ----
+constexpr int EB_CHUNK = 2048;
+__global__ __launch_bounds__(128) void k_embbwd_part(const float* __restrict__ dX, long long ldx, const int64_t* __restrict__ tok,
+                                                     long long NT, int E, float* __restrict__ part)
+{
+    // grid (V, nchunks); block covers E columns in strides of 128
+    const int v = blockIdx.x;
+    const long long r0 = (long long)blockIdx.y * EB_CHUNK;
+    const long long r1 = r0 + EB_CHUNK < NT ? r0 + EB_CHUNK : NT;
+    for (int c = threadIdx.x; c < E; c += 128) {
+        float acc = 0.f;
+        for (long long r = r0; r < r1; ++r)
+            if (tok[r] == v) acc += dX[r * ldx + c];
+        part[((long long)blockIdx.y * gridDim.x + v) * E + c] = acc;
+    }
+}
+__global__ __launch_bounds__(256) void k_embbwd_final(const float* __restrict__ part, int nchunks, int V, int E, int padding_idx,
+                                                      float* __restrict__ dEmb)
+{
+    const long long total = (long long)V * E;
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+        const int v = (int)(e / E);
+        double acc = 0.0;
+        for (int p = 0; p < nchunks; ++p) acc += (double)part[(long long)p * total + e];
+        dEmb[e] = v == padding_idx ? 0.f : (float)acc;
+    }
+}
+
+// ---- K2: cross-entropy over packed logits, ignore_index, mean over valid ----
+// one wave per row; block of 256 = 4 rows.  Writes lse[row] and per-block partials.
+__global__ __launch_bounds__(256) void k_ce_rows(const float* __restrict__ logits, long long ldl, const int64_t* __restrict__ tgt,
+                                                 long long rows, int V, long long ignore_index,
+                                                 float* __restrict__ lse, double* __restrict__ part_loss,
+                                                 unsigned int* __restrict__ part_cnt)
+{
+    __shared__ double sl[4];
+    __shared__ unsigned int sc[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    double myloss = 0.0;
+    unsigned int mycnt = 0;
+    for (long long row = (long long)blockIdx.x * 4 + wave; row < rows; row += (long long)gridDim.x * 4) {
+        const float* x = logits + row * ldl;
+        float m = -INFINITY;
+        for (int c = lane; c < V; c += 64) m = fmaxf(m, x[c]);
+        m = ppk_wave_max(m);
+        float s = 0.f;
+        for (int c = lane; c < V; c += 64) s += expf(x[c] - m);
+        s = ppk_wave_sum(s);
+        const float l = m + logf(s);
+        if (lane == 0) {
+            lse[row] = l;
+            const long long t = tgt[row];
+            if (t != ignore_index && t >= 0 && t < V) {
+                myloss += (double)(l - x[t]);
+                mycnt += 1;
+            }
+        }
+    }
+    if (lane == 0) { sl[wave] = myloss; sc[wave] = mycnt; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        part_loss[blockIdx.x] = (sl[0] + sl[1]) + (sl[2] + sl[3]);
+        part_cnt[blockIdx.x] = sc[0] + sc[1] + sc[2] + sc[3];
+    }
+}
+__global__ __launch_bounds__(256) void k_ce_final(const double* __restrict__ part_loss, const unsigned int* __restrict__ part_cnt,
+                                                  int nparts, float* __restrict__ loss, float* __restrict__ count)
+{
+    __shared__ double sl[4];
+    __shared__ unsigned int sc[4];
+    double a = 0.0;
+    unsigned int c = 0;
+    for (int p = threadIdx.x; p < nparts; p += 256) { a += part_loss[p]; c += part_cnt[p]; }
+    a = ppk_wave_sum_d(a);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
+    if ((threadIdx.x & 63) == 0) { sl[threadIdx.x >> 6] = a; sc[threadIdx.x >> 6] = c; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const double tot = (sl[0] + sl[1]) + (sl[2] + sl[3]);
+        const unsigned int n = sc[0] + sc[1] + sc[2] + sc[3];
+        loss[0] = (float)(tot / (double)n);     // n == 0 -> nan, like torch
+        count[0] = (float)n;
+    }
+}
+__global__ __launch_bounds__(256) void k_ce_bwd(const float* __restrict__ logits, long long ldl, const int64_t* __restrict__ tgt,
+                                                long long rows, int V, long long ignore_index, const float* __restrict__ lse,
+                                                const float* __restrict__ count, const float* __restrict__ dloss,
+                                                float* __restrict__ dlogits, long long ldd)
+{
+    const float scale = dloss[0] / count[0];
+    const long long total = rows * V;
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+        const long long row = e / V;
+        const int c = (int)(e % V);
+        const long long t = tgt[row];
+        float g = 0.f;
+        if (t != ignore_index && t >= 0 && t < V) g = scale * (expf(logits[row * ldl + c] - lse[row]) - (c == t ? 1.f : 0.f));
+        dlogits[row * ldd + c] = g;
+    }
+}
+
+// ---- K3: reparameterise + KL ---------------------------------------------------
+__global__ __launch_bounds__(256) void k_reparam_fwd(const float* __restrict__ mu, const float* __restrict__ logvar,
+                                                     const float* __restrict__ eps, long long n, float* __restrict__ z,
+                                                     double* __restrict__ part)
+{
+    __shared__ double sl[4];
+    double acc = 0.0;
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long long)gridDim.x * 256) {
+        const float m = mu[e], lv = logvar[e];
+        const float sd = expf(0.5f * lv);
+        z[e] = fmaf(eps[e], sd, m);
+        acc += (double)(1.0f + lv - m * m - expf(lv));
+    }
+    acc = ppk_wave_sum_d(acc);
+    if ((threadIdx.x & 63) == 0) sl[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) part[blockIdx.x] = (sl[0] + sl[1]) + (sl[2] + sl[3]);
+}
+__global__ __launch_bounds__(64) void k_kl_final(const double* __restrict__ part, int nparts, float* __restrict__ kl)
+{
+    double a = 0.0;
+    for (int p = threadIdx.x; p < nparts; p += 64) a += part[p];
+    a = ppk_wave_sum_d(a);
+    if (threadIdx.x == 0) kl[0] = (float)(-0.5 * a);
+}
+__global__ __launch_bounds__(256) void k_reparam_bwd(const float* __restrict__ mu, const float* __restrict__ logvar,
+                                                     const float* __restrict__ eps, long long n, const float* __restrict__ dz,
+                                                     const float* __restrict__ dkl, float* __restrict__ dmu, float* __restrict__ dlogvar)
+{
+    const float gk = dkl ? dkl[0] : 0.f;
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long long)gridDim.x * 256) {
+        const float m = mu[e], lv = logvar[e];
+        const float g = dz ? dz[e] : 0.f;
+        dmu[e] = g + gk * m;
+        dlogvar[e] = g * eps[e] * 0.5f * expf(0.5f * lv) + gk * 0.5f * (expf(lv) - 1.0f);
+    }
+}
+
+// ---- flat Adam (torch.optim.Adam semantics, no amsgrad) --------------------------
+__global__ __launch_bounds__(256) void k_adam(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                              float* __restrict__ v, long long n, float lr, float b1, float b2, float eps,
+                                              float wd, float bc1, float bc2_sqrt)
+{
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long long)gridDim.x * 256) {
+        float gr = g[e];
+        const float pe = p[e];
+        if (wd != 0.f) gr = fmaf(wd, pe, gr);
+        const float me = b1 * m[e] + (1.0f - b1) * gr;
+        const float ve = b2 * v[e] + (1.0f - b2) * gr * gr;
+        m[e] = me;
+        v[e] = ve;
+        const float denom = sqrtf(ve) / bc2_sqrt + eps;
+        p[e] = pe - (lr / bc1) * (me / denom);
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int ppk_gather_rows(const float* src, int64_t ld_src, int64_t src_rows, const int64_t* idx, int64_t n_rows, int64_t width,
+                    float* dst, int64_t ld_dst, hipStream_t stream)
+{
+    if (n_rows == 0 || width == 0) return PPK_OK;
+    if (!src || !idx || !dst) PPK_FAIL(PPK_ERR_NULL, "gather_rows: null pointer");
+    if (n_rows < 0 || width < 0 || ld_src < width || ld_dst < width) PPK_FAIL(PPK_ERR_SHAPE, "gather_rows: bad sizes");
+    k_rows<false><<<dim3(grid_for(n_rows * width)), dim3(256), 0, stream>>>(src, ld_src, idx, n_rows, (int)width, src_rows, dst, ld_dst, 0);
+    PPK_CHECK_LAUNCH("k_rows<gather>");
+    return PPK_OK;
+}
+
+int ppk_scatter_rows(const float* src, int64_t ld_src, const int64_t* idx, int64_t n_rows, int64_t width,
+                     float* dst, int64_t ld_dst, int64_t dst_rows, hipStream_t stream)
+{
+    if (n_rows == 0 || width == 0) return PPK_OK;
+    if (!src || !idx || !dst) PPK_FAIL(PPK_ERR_NULL, "scatter_rows: null pointer");
+    if (n_rows < 0 || width < 0 || ld_src < width || ld_dst < width) PPK_FAIL(PPK_ERR_SHAPE, "scatter_rows: bad sizes");
+    k_rows<true><<<dim3(grid_for(n_rows * width)), dim3(256), 0, stream>>>(src, ld_src, idx, n_rows, (int)width, 0, dst, ld_dst, dst_rows);
+    PPK_CHECK_LAUNCH("k_rows<scatter>");
+    return PPK_OK;
+}
+
+size_t ppk_colsum_workspace_bytes(int64_t rows, int64_t cols)
+{
+    if (rows <= 0 || cols <= 0) return 0;
+    return ppk_align_up(sizeof(float) * (size_t)((rows + CS_CHUNK - 1) / CS_CHUNK) * (size_t)cols, 256);
+}
+
+// out[c] = beta * out[c] + sum_r A[r, c]
+int ppk_colsum(const float* A, int64_t lda, int64_t rows, int64_t cols, float beta, float* out,
+               void* workspace, size_t ws_bytes, hipStream_t stream)
+{
+    if (cols == 0) return PPK_OK;
+    if (!A || !out || !workspace) PPK_FAIL(PPK_ERR_NULL, "colsum: null pointer");
+    if (rows < 1 || cols < 1 || lda < cols) PPK_FAIL(PPK_ERR_SHAPE, "colsum: bad sizes");
+    if (ws_bytes < ppk_colsum_workspace_bytes(rows, cols)) PPK_FAIL(PPK_ERR_WS, "colsum: workspace too small");
+    const int nparts = (int)((rows + CS_CHUNK - 1) / CS_CHUNK);
+    if (nparts > 65535) PPK_FAIL(PPK_ERR_UNSUP, "colsum: too many rows");
+    dim3 grid((unsigned)((cols + 255) / 256), (unsigned)nparts);
+    k_colsum_part<<<grid, dim3(256), 0, stream>>>(A, lda, rows, (int)cols, (float*)workspace);
+    PPK_CHECK_LAUNCH("k_colsum_part");
+    k_colsum_final<<<dim3(grid.x), dim3(256), 0, stream>>>((const float*)workspace, nparts, (int)cols, beta, out);
+    PPK_CHECK_LAUNCH("k_colsum_final");
+    return PPK_OK;
+}
+
+size_t ppk_embedding_bwd_workspace_bytes(int64_t NT, int64_t V, int64_t E)
+{
+    if (NT <= 0 || V <= 0 || E <= 0) return 0;
+    return ppk_align_up(sizeof(float) * (size_t)((NT + EB_CHUNK - 1) / EB_CHUNK) * (size_t)V * (size_t)E, 256);
+}
+
+// dEmb [V, E] (overwritten); row padding_idx is zero (nn.Embedding(padding_idx=...)); pass -1 for none
+int ppk_embedding_bwd(const float* dX, int64_t ldx, const int64_t* tokens, int64_t NT, int64_t V, int64_t E,
+                      int64_t padding_idx, float* dEmb, void* workspace, size_t ws_bytes, hipStream_t stream)
+{
+    if (!dX || !tokens || !dEmb || !workspace) PPK_FAIL(PPK_ERR_NULL, "embedding_bwd: null pointer");
+    if (NT < 1 || V < 1 || E < 1 || ldx < E) PPK_FAIL(PPK_ERR_SHAPE, "embedding_bwd: bad sizes");
+    if (ws_bytes < ppk_embedding_bwd_workspace_bytes(NT, V, E)) PPK_FAIL(PPK_ERR_WS, "embedding_bwd: workspace too small");
+    const int nchunks = (int)((NT + EB_CHUNK - 1) / EB_CHUNK);
+    if (nchunks > 65535) PPK_FAIL(PPK_ERR_UNSUP, "embedding_bwd: too many rows");
+    k_embbwd_part<<<dim3((unsigned)V, (unsigned)nchunks), dim3(128), 0, stream>>>(dX, ldx, tokens, NT, (int)E, (float*)workspace);
+    PPK_CHECK_LAUNCH("k_embbwd_part");
+    k_embbwd_final<<<dim3(grid_for(V * E)), dim3(256), 0, stream>>>((const float*)workspace, nchunks, (int)V, (int)E, (int)padding_idx, dEmb);
+    PPK_CHECK_LAUNCH("k_embbwd_final");
+    return PPK_OK;
+}
+
+static int ce_blocks(int64_t rows) { long long b = (rows + 3) / 4; return (int)(b < 2048 ? (b < 1 ? 1 : b) : 2048); }
+
+size_t ppk_ce_workspace_bytes(int64_t rows)
+{
+    if (rows <= 0) return 0;
+    return ppk_align_up(sizeof(float) * (size_t)rows, 256) + ppk_align_up(sizeof(double) * 2048, 256) + ppk_align_up(sizeof(unsigned) * 2048, 256) + 256;
+}
+
+// loss[0] = mean over rows with target != ignore_index of (logsumexp(logits[row]) - logits[row, target])
+// The workspace keeps lse / count for ppk_ce_bwd.
+int ppk_ce_fwd(const float* logits, int64_t ldl, const int64_t* targets, int64_t rows, int64_t V, int64_t ignore_index,
+               float* loss, void* workspace, size_t ws_bytes, hipStream_t stream)
+{
+    if (!logits || !targets || !loss || !workspace) PPK_FAIL(PPK_ERR_NULL, "ce_fwd: null pointer");
+    if (rows < 1 || V < 1 || ldl < V) PPK_FAIL(PPK_ERR_SHAPE, "ce_fwd: bad sizes");
+    if (ws_bytes < ppk_ce_workspace_bytes(rows)) PPK_FAIL(PPK_ERR_WS, "ce_fwd: workspace too small");
+    char* cur = (char*)workspace;
+    float* lse = (float*)ppk_carve(cur, sizeof(float) * (size_t)rows);
+    double* pl = (double*)ppk_carve(cur, sizeof(double) * 2048);
+    unsigned* pc = (unsigned*)ppk_carve(cur, sizeof(unsigned) * 2048);
+    float* count = (float*)ppk_carve(cur, 256);
+    const int nb = ce_blocks(rows);
+    k_ce_rows<<<dim3(nb), dim3(256), 0, stream>>>(logits, ldl, targets, rows, (int)V, ignore_index, lse, pl, pc);
+    PPK_CHECK_LAUNCH("k_ce_rows");
+    k_ce_final<<<dim3(1), dim3(256), 0, stream>>>(pl, pc, nb, loss, count);
+    PPK_CHECK_LAUNCH("k_ce_final");
+    return PPK_OK;
+}
+
+int ppk_ce_bwd(const float* logits, int64_t ldl, const int64_t* targets, int64_t rows, int64_t V, int64_t ignore_index,
+               const float* dloss, float* dlogits, int64_t ldd, const void* workspace, size_t ws_bytes, hipStream_t stream)
+{
+    if (!logits || !targets || !dloss || !dlogits || !workspace) PPK_FAIL(PPK_ERR_NULL, "ce_bwd: null pointer");
+    if (rows < 1 || V < 1 || ldl < V || ldd < V) PPK_FAIL(PPK_ERR_SHAPE, "ce_bwd: bad sizes");
+    if (ws_bytes < ppk_ce_workspace_bytes(rows)) PPK_FAIL(PPK_ERR_WS, "ce_bwd: workspace too small");
+    char* cur = (char*)workspace;
+    const float* lse = (const float*)ppk_carve(cur, sizeof(float) * (size_t)rows);
+    (void)ppk_carve(cur, sizeof(double) * 2048);
+    (void)ppk_carve(cur, sizeof(unsigned) * 2048);
+    const float* count = (const float*)ppk_carve(cur, 256);
+    k_ce_bwd<<<dim3(grid_for(rows * V)), dim3(256), 0, stream>>>(logits, ldl, targets, rows, (int)V, ignore_index, lse, count, dloss, dlogits, ldd);
+    PPK_CHECK_LAUNCH("k_ce_bwd");
+    return PPK_OK;
+}
+
+size_t ppk_reparam_workspace_bytes(int64_t n)
+{
+    (void)n;
+    return ppk_align_up(sizeof(double) * 1024, 256);
+}
+
+// z = eps * exp(0.5 logvar) + mu ;  kl[0] = -0.5 sum(1 + logvar - mu^2 - exp(logvar))   (kl may be NULL)
+int ppk_reparam_fwd(const float* mu, const float* logvar, const float* eps, int64_t n, float* z, float* kl,
+                    void* workspace, size_t ws_bytes, hipStream_t stream)
+{
+    if (!mu || !logvar || !eps || !z || !workspace) PPK_FAIL(PPK_ERR_NULL, "reparam_fwd: null pointer");
+    if (n < 1) PPK_FAIL(PPK_ERR_SHAPE, "reparam_fwd: n < 1");
+    if (ws_bytes < ppk_reparam_workspace_bytes(n)) PPK_FAIL(PPK_ERR_WS, "reparam_fwd: workspace too small");
+    const unsigned nb = grid_for(n, 1024);
+    k_reparam_fwd<<<dim3(nb), dim3(256), 0, stream>>>(mu, logvar, eps, n, z, (double*)workspace);
+    PPK_CHECK_LAUNCH("k_reparam_fwd");
+    if (kl) {
+        k_kl_final<<<dim3(1), dim3(64), 0, stream>>>((const double*)workspace, (int)nb, kl);
+        PPK_CHECK_LAUNCH("k_kl_final");
+    }
+    return PPK_OK;
+}
+
+// dmu = dz + dkl * mu ; dlogvar = dz * eps * 0.5 exp(0.5 logvar) + dkl * 0.5 (exp(logvar) - 1)   (dz or dkl may be NULL)
+int ppk_reparam_bwd(const float* mu, const float* logvar, const float* eps, int64_t n, const float* dz, const float* dkl,
+                    float* dmu, float* dlogvar, hipStream_t stream)
+{
+    if (!mu || !logvar || !eps || !dmu || !dlogvar) PPK_FAIL(PPK_ERR_NULL, "reparam_bwd: null pointer");
+    if (n < 1) PPK_FAIL(PPK_ERR_SHAPE, "reparam_bwd: n < 1");
+    k_reparam_bwd<<<dim3(grid_for(n)), dim3(256), 0, stream>>>(mu, logvar, eps, n, dz, dkl, dmu, dlogvar);
+    PPK_CHECK_LAUNCH("k_reparam_bwd");
+    return PPK_OK;
+}
+
+// One Adam step over flat fp32 buffers (torch.optim.Adam defaults semantics; step is 1-based).
+int ppk_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
+                  float lr, float beta1, float beta2, float eps, float weight_decay, int64_t step, hipStream_t stream)
+{
+    if (n == 0) return PPK_OK;
+    if (!param || !grad || !exp_avg || !exp_avg_sq) PPK_FAIL(PPK_ERR_NULL, "adam_step: null pointer");
+    if (n < 0 || step < 1) PPK_FAIL(PPK_ERR_SHAPE, "adam_step: bad n / step");
+    const double bc1 = 1.0 - pow((double)beta1, (double)step);
+    const double bc2 = 1.0 - pow((double)beta2, (double)step);
+    k_adam<<<dim3(grid_for(n)), dim3(256), 0, stream>>>(param, grad, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay,
+                                                        (float)bc1, (float)sqrt(bc2));
+    PPK_CHECK_LAUNCH("k_adam");
+    return PPK_OK;
+}
+
+}  // extern "C"

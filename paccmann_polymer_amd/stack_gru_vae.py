@@ -1,0 +1,480 @@
+"""Stack-augmented GRU VAE (encoder / decoder / TeacherVAE) on HIP kernels.
+
+Host-side mirror of the slice of `paccmann_chemistry@0.0.4` that the
+reference's hot path uses (the package itself is absent offline; semantics per
+SURVEY.md Appendix B, CPU restatement in oracle/stackgru_ref.py):
+
+  reference call sites
+    paccmann_polymer/models/paccmann_encoder.py:52-59   StackGRUEncoder(params), StackGRUDecoder(params), TeacherVAE(enc, dec)
+    paccmann_polymer/models/paccmann_encoder.py:87-88   ._update_batch_size(int)
+    paccmann_polymer/models/paccmann_encoder.py:166-168 .encode / .reparameterize / .decode
+    .../chem_reactions/reactions_vae.py:177             .encoder.set_batch_mode('packed')
+    .../chem_reactions/reactions_vae.py:209             .save(path)
+
+The nn.Module objects are PARAMETER CONTAINERS with upstream-compatible
+`state_dict` keys (`encoder.gru.weight_ih_l0`, `decoder.output_layer.weight`, …);
+their torch `forward`s are never used.  All arithmetic runs through libppk.so:
+K1 sequence kernels + fp32-MFMA GEMMs, K2 cross-entropy, K3 reparameterise+KL,
+each with a hand-written backward wired in through `torch.autograd.Function`.
+
+Restrictions of the HIP path (raise instead of silently falling back):
+`use_stack=True`, `bidirectional=False`, `dropout == 0` in training mode,
+packed batches (`PackedSequence`), fp32.
+"""
+import ctypes
+from typing import Optional
+
+import torch
+import torch.nn as nn
+from torch.nn.utils.rnn import PackedSequence
+
+from . import _C
+
+_lib = _C.lib
+
+
+def _ws(nbytes, device):
+    return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+
+
+def _ptr_array(tensors):
+    arr = (ctypes.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
+    return arr
+
+
+# --------------------------------------------------------------------------
+# small autograd ops on the C-ABI
+# --------------------------------------------------------------------------
+class _Linear(torch.autograd.Function):
+    """y = x @ W^T + b  (fp32 MFMA GEMM; backward: NN / TN GEMMs + column sum)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        _C.require_gpu(x, weight, bias)
+        x = x.contiguous()
+        M, K = x.shape
+        N = weight.shape[0]
+        y = torch.empty(M, N, dtype=torch.float32, device=x.device)
+        _C.check(_lib.ppk_gemm_f32(0, 1, M, N, K, 1.0, _C.p(x), x.stride(0), _C.p(weight), weight.stride(0), 0.0,
+                                   _C.p(y), N, _C.p(bias), None, 0, _C.stream()))
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        dy = dy.contiguous()
+        M, K = x.shape
+        N = weight.shape[0]
+        dev = x.device
+        dx = torch.empty_like(x)
+        _C.check(_lib.ppk_gemm_f32(0, 0, M, K, N, 1.0, _C.p(dy), N, _C.p(weight), weight.stride(0), 0.0,
+                                   _C.p(dx), K, None, None, 0, _C.stream()))
+        dw = torch.empty(N, K, dtype=torch.float32, device=dev)
+        wsb = _lib.ppk_gemm_f32_workspace_bytes(N, K, M)
+        ws = _ws(wsb, dev)
+        _C.check(_lib.ppk_gemm_f32(1, 0, N, K, M, 1.0, _C.p(dy), N, _C.p(x), K, 0.0,
+                                   _C.p(dw), K, None, _C.p(ws), wsb, _C.stream()))
+        db = None
+        if ctx.has_bias:
+            db = torch.empty(N, dtype=torch.float32, device=dev)
+            cb = _lib.ppk_colsum_workspace_bytes(M, N)
+            cws = _ws(cb, dev)
+            _C.check(_lib.ppk_colsum(_C.p(dy), N, M, N, 0.0, _C.p(db), _C.p(cws), cb, _C.stream()))
+        return dx, dw, db
+
+
+class _GatherRows(torch.autograd.Function):
+    """out[i] = src[idx[i]] with DISTINCT idx (backward = scatter into zeros)."""
+
+    @staticmethod
+    def forward(ctx, src, idx):
+        _C.require_gpu(src, idx)
+        src = src.contiguous()
+        n, w = idx.numel(), src.shape[1]
+        out = torch.empty(n, w, dtype=torch.float32, device=src.device)
+        _C.check(_lib.ppk_gather_rows(_C.p(src), src.stride(0), src.shape[0], _C.p(idx), n, w, _C.p(out), w, _C.stream()))
+        ctx.save_for_backward(idx)
+        ctx.src_rows = src.shape[0]
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (idx,) = ctx.saved_tensors
+        dout = dout.contiguous()
+        n, w = dout.shape
+        dsrc = torch.zeros(ctx.src_rows, w, dtype=torch.float32, device=dout.device)
+        _C.check(_lib.ppk_scatter_rows(_C.p(dout), w, _C.p(idx), n, w, _C.p(dsrc), w, ctx.src_rows, _C.stream()))
+        return dsrc, None
+
+
+class _CrossEntropy(torch.autograd.Function):
+    """K2: mean CE over rows with target != ignore_index."""
+
+    @staticmethod
+    def forward(ctx, logits, targets, ignore_index):
+        _C.require_gpu(logits, targets)
+        logits = logits.contiguous()
+        rows, V = logits.shape
+        wsb = _lib.ppk_ce_workspace_bytes(rows)
+        ws = _ws(wsb, logits.device)
+        loss = torch.empty(1, dtype=torch.float32, device=logits.device)
+        _C.check(_lib.ppk_ce_fwd(_C.p(logits), V, _C.p(targets), rows, V, ignore_index, _C.p(loss), _C.p(ws), wsb, _C.stream()))
+        ctx.save_for_backward(logits, targets, ws)
+        ctx.ignore_index = ignore_index
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, dloss):
+        logits, targets, ws = ctx.saved_tensors
+        rows, V = logits.shape
+        dl = dloss.to(torch.float32).reshape(1).contiguous()
+        dlogits = torch.empty_like(logits)
+        _C.check(_lib.ppk_ce_bwd(_C.p(logits), V, _C.p(targets), rows, V, ctx.ignore_index, _C.p(dl), _C.p(dlogits), V,
+                                 _C.p(ws), ws.numel(), _C.stream()))
+        return dlogits, None, None
+
+
+class _ReparamKL(torch.autograd.Function):
+    """K3: z = eps * exp(0.5 logvar) + mu and KL = -0.5 sum(1 + logvar - mu^2 - exp(logvar))."""
+
+    @staticmethod
+    def forward(ctx, mu, logvar, eps):
+        _C.require_gpu(mu, logvar, eps)
+        mu, logvar, eps = mu.contiguous(), logvar.contiguous(), eps.contiguous()
+        n = mu.numel()
+        z = torch.empty_like(mu)
+        kl = torch.empty(1, dtype=torch.float32, device=mu.device)
+        wsb = _lib.ppk_reparam_workspace_bytes(n)
+        ws = _ws(wsb, mu.device)
+        _C.check(_lib.ppk_reparam_fwd(_C.p(mu), _C.p(logvar), _C.p(eps), n, _C.p(z), _C.p(kl), _C.p(ws), wsb, _C.stream()))
+        ctx.save_for_backward(mu, logvar, eps)
+        return z, kl.reshape(())
+
+    @staticmethod
+    def backward(ctx, dz, dkl):
+        mu, logvar, eps = ctx.saved_tensors
+        n = mu.numel()
+        dz = dz.contiguous() if dz is not None else None
+        dk = dkl.to(torch.float32).reshape(1).contiguous() if dkl is not None else None
+        dmu, dlv = torch.empty_like(mu), torch.empty_like(logvar)
+        _C.check(_lib.ppk_reparam_bwd(_C.p(mu), _C.p(logvar), _C.p(eps), n, _C.p(dz), _C.p(dk), _C.p(dmu), _C.p(dlv), _C.stream()))
+        return dmu, dlv, None
+
+
+def reparameterize_kl(mu, logvar, eps):
+    """(z, KL) — fused K3 op (cora/vae.py:31-34,50)."""
+    return _ReparamKL.apply(mu, logvar, eps)
+
+
+def linear(x, weight, bias=None):
+    return _Linear.apply(x, weight, bias)
+
+
+class _StackGRUSeq(torch.autograd.Function):
+    """K1: the whole packed StackGRU sequence.  Returns the top layer's output of
+    every step, [NT, H] in packed order."""
+
+    @staticmethod
+    def forward(ctx, tokens, batch_sizes, dims, h0, emb, wc, bc, wsi, bsi, *gru):
+        V, E, H, L, W, D, pad = dims
+        _C.require_gpu(tokens, h0, emb, wc, bc, wsi, bsi, *gru)
+        dev = emb.device
+        T = batch_sizes.numel()
+        B = int(batch_sizes[0])
+        NT = int(tokens.numel())
+        I0 = E + W
+        ldx = (I0 + 3) // 4 * 4
+        ldcs = (3 + W + 3) // 4 * 4
+        w_ih = [gru[4 * l + 0] for l in range(L)]
+        w_hh = [gru[4 * l + 1] for l in range(L)]
+        b_ih = [gru[4 * l + 2] for l in range(L)]
+        b_hh = [gru[4 * l + 3] for l in range(L)]
+        # stack heads as one [3+W, H] operand; layer-0 input weights padded to ldx columns
+        wcs = torch.cat([wc, wsi], dim=0).contiguous()
+        bcs = torch.cat([bc, bsi], dim=0).contiguous()
+        if ldx != I0:
+            w0 = torch.zeros(3 * H, ldx, dtype=torch.float32, device=dev)
+            w0[:, :I0] = w_ih[0]
+        else:
+            w0 = w_ih[0].contiguous()
+        w_ih_use = [w0] + [w.contiguous() for w in w_ih[1:]]
+        w_hh_use = [w.contiguous() for w in w_hh]
+        h0 = h0.contiguous()
+
+        f32 = dict(dtype=torch.float32, device=dev)
+        X = torch.empty(NT, ldx, **f32)
+        Hs = torch.empty(L, NT, H, **f32)
+        HP = torch.empty(L, NT, H, **f32)
+        gates = torch.empty(L, NT, 4 * H, **f32)
+        S = torch.empty(NT, D, W, **f32)
+        CS = torch.empty(NT, ldcs, **f32)
+        wsb = _lib.ppk_stackgru_seq_fwd_workspace_bytes(B, H, W)
+        ws = _ws(wsb, dev)
+        bs_host = batch_sizes.contiguous()
+        _C.check(_lib.ppk_stackgru_seq_fwd(
+            T, ctypes.c_void_p(bs_host.data_ptr()), B, NT, V, E, H, L, W, D,
+            _C.p(tokens), _C.p(emb), _ptr_array(w_ih_use), ldx, _ptr_array(w_hh_use),
+            _ptr_array(b_ih), _ptr_array(b_hh), _C.p(wcs), _C.p(bcs), _C.p(h0),
+            _C.p(X), ldx, _C.p(Hs), _C.p(HP), _C.p(gates), _C.p(S), _C.p(CS), ldcs,
+            _C.p(ws), wsb, _C.stream()))
+        ctx.save_for_backward(tokens, X, Hs, HP, gates, S, CS, wcs, *w_ih_use, *w_hh_use)
+        ctx.bs_host = bs_host
+        ctx.dims = (V, E, H, L, W, D, T, B, NT, ldx, ldcs, I0)
+        ctx.padding_idx = -1 if pad is None else int(pad)
+        return Hs[L - 1]
+
+    @staticmethod
+    def backward(ctx, dHtop):
+        V, E, H, L, W, D, T, B, NT, ldx, ldcs, I0 = ctx.dims
+        saved = ctx.saved_tensors
+        tokens, X, Hs, HP, gates, S, CS, wcs = saved[:8]
+        w_ih_use = list(saved[8:8 + L])
+        w_hh_use = list(saved[8 + L:8 + 2 * L])
+        dev = X.device
+        f32 = dict(dtype=torch.float32, device=dev)
+        dHtop = dHtop.contiguous()
+        dX = torch.empty(NT, ldx, **f32)
+        DGI = torch.empty(L, NT, 3 * H, **f32)
+        DGH = torch.empty(L, NT, 3 * H, **f32)
+        DCS = torch.empty(NT, ldcs, **f32)
+        dh0 = torch.empty(L, B, H, **f32)
+        wsb = _lib.ppk_stackgru_seq_bwd_workspace_bytes(B, H, W, D)
+        ws = _ws(wsb, dev)
+        st = _C.stream()
+        _C.check(_lib.ppk_stackgru_seq_bwd(
+            T, ctypes.c_void_p(ctx.bs_host.data_ptr()), B, NT, V, E, H, L, W, D,
+            _ptr_array(w_ih_use), ldx, _ptr_array(w_hh_use), _C.p(wcs),
+            _C.p(HP), _C.p(gates), _C.p(S), _C.p(CS), ldcs,
+            _C.p(dHtop), _C.p(dX), ldx, _C.p(DGI), _C.p(DGH), _C.p(DCS), _C.p(dh0),
+            _C.p(ws), wsb, st))
+
+        # ---- weight gradients: single large TN GEMMs over the saved activations
+        gws_b = _lib.ppk_gemm_f32_workspace_bytes(3 * H, max(H, I0), NT)
+        gws = _ws(gws_b, dev)
+        cws_b = _lib.ppk_colsum_workspace_bytes(NT, 3 * H)
+        cws = _ws(cws_b, dev)
+
+        def tn(A, lda, M, Bm, ldb, N):
+            out = torch.empty(M, N, **f32)
+            _C.check(_lib.ppk_gemm_f32(1, 0, M, N, NT, 1.0, _C.p(A), lda, _C.p(Bm), ldb, 0.0,
+                                       _C.p(out), N, None, _C.p(gws), gws_b, st))
+            return out
+
+        def colsum(A, lda, C):
+            out = torch.empty(C, **f32)
+            _C.check(_lib.ppk_colsum(_C.p(A), lda, NT, C, 0.0, _C.p(out), _C.p(cws), cws_b, st))
+            return out
+
+        gru_grads = []
+        for l in range(L):
+            inp, ldin, Il = (X, ldx, I0) if l == 0 else (Hs[l - 1], H, H)
+            gru_grads += [
+                tn(DGI[l], 3 * H, 3 * H, inp, ldin, Il),
+                tn(DGH[l], 3 * H, 3 * H, HP[l], H, H),
+                colsum(DGI[l], 3 * H, 3 * H),
+                colsum(DGH[l], 3 * H, 3 * H),
+            ]
+        dwcs = tn(DCS, ldcs, 3 + W, HP[L - 1], H, H)
+        dbcs = colsum(DCS, ldcs, 3 + W)
+        demb = torch.empty(V, E, **f32)
+        eb = _lib.ppk_embedding_bwd_workspace_bytes(NT, V, E)
+        ews = _ws(eb, dev)
+        _C.check(_lib.ppk_embedding_bwd(_C.p(dX), ldx, _C.p(tokens), NT, V, E, ctx.padding_idx,
+                                        _C.p(demb), _C.p(ews), eb, st))
+        return (None, None, None, dh0, demb, dwcs[:3], dbcs[:3], dwcs[3:], dbcs[3:], *gru_grads)
+
+
+# --------------------------------------------------------------------------
+# modules (parameter containers + HIP forward)
+# --------------------------------------------------------------------------
+class StackGRU(nn.Module):
+
+    def __init__(self, params):
+        super().__init__()
+        self.params = dict(params)
+        p = self.params
+        self.vocab_size = p['vocab_size']
+        self.embedding_size = p['embedding_size']
+        self.rnn_cell_size = p['rnn_cell_size']
+        self.n_layers = p['n_layers']
+        self.stack_width = p['stack_width']
+        self.stack_depth = p['stack_depth']
+        self.dropout = p.get('dropout', 0.0)
+        self.padding_index = p.get('padding_index', 0)
+        self.batch_size = p.get('batch_size', 1)
+        self.batch_mode = str(p.get('batch_mode', 'packed')).lower()
+        self.use_stack = p.get('use_stack', True)
+        self.bidirectional = p.get('bidirectional', False)
+        if not self.use_stack or self.bidirectional:
+            raise NotImplementedError('the HIP path implements use_stack=True, bidirectional=False')
+        self.embedding = nn.Embedding(self.vocab_size, self.embedding_size, padding_idx=self.padding_index)
+        self.gru = nn.GRU(self.embedding_size + self.stack_width, self.rnn_cell_size, self.n_layers,
+                          dropout=self.dropout)
+        self.stack_controls_layer = nn.Linear(self.rnn_cell_size, 3)
+        self.stack_input_layer = nn.Linear(self.rnn_cell_size, self.stack_width)
+
+    # upstream API kept for drop-in callers (reactions_vae.py:62-63,177)
+    def _update_batch_size(self, batch_size: int):
+        self.batch_size = int(batch_size)
+
+    def set_batch_mode(self, mode: str):
+        mode = str(mode).lower()
+        if mode not in ('packed', 'padded'):
+            raise NotImplementedError(f'Unknown batch mode: {mode}')
+        self.batch_mode = mode
+
+    def _dims(self):
+        return (self.vocab_size, self.embedding_size, self.rnn_cell_size, self.n_layers,
+                self.stack_width, self.stack_depth, self.padding_index)
+
+    def _gru_params(self):
+        out = []
+        for l in range(self.n_layers):
+            out += [getattr(self.gru, f'weight_ih_l{l}'), getattr(self.gru, f'weight_hh_l{l}'),
+                    getattr(self.gru, f'bias_ih_l{l}'), getattr(self.gru, f'bias_hh_l{l}')]
+        return out
+
+    def _run_sequence(self, packed: PackedSequence, h0):
+        """-> top-layer outputs [NT, H] in packed order."""
+        if not isinstance(packed, PackedSequence):
+            raise TypeError('the HIP path takes PackedSequence batches (batch_mode="packed")')
+        if self.training and self.dropout > 0:
+            raise NotImplementedError('dropout > 0 in training mode is not implemented in the HIP path')
+        dev = self.embedding.weight.device
+        tokens = packed.data
+        if tokens.dim() != 1:
+            tokens = tokens.reshape(-1)
+        if not tokens.is_cuda:
+            if tokens.numel() and (int(tokens.max()) >= self.vocab_size or int(tokens.min()) < 0):
+                raise IndexError('token index out of range')
+            tokens = tokens.to(dev)
+        tokens = tokens.to(torch.int64).contiguous()
+        bs = packed.batch_sizes.to('cpu', torch.int64)
+        return _StackGRUSeq.apply(tokens, bs, self._dims(), h0, self.embedding.weight,
+                                  self.stack_controls_layer.weight, self.stack_controls_layer.bias,
+                                  self.stack_input_layer.weight, self.stack_input_layer.bias,
+                                  *self._gru_params())
+
+
+def _require_packed(x):
+    if not isinstance(x, PackedSequence):
+        raise TypeError('the HIP path takes PackedSequence batches (batch_mode="packed")')
+
+
+def _final_row_index(packed: PackedSequence, device):
+    """Packed row of each ORIGINAL sample's last step."""
+    bs = packed.batch_sizes.to(torch.int64)
+    T = bs.numel()
+    B = int(bs[0])
+    off = torch.zeros(T + 1, dtype=torch.int64)
+    off[1:] = torch.cumsum(bs, 0)
+    # length of sorted sequence s = number of steps with batch_size > s
+    lengths = (bs.unsqueeze(1) > torch.arange(B).unsqueeze(0)).sum(0)
+    fin_sorted = off[lengths - 1] + torch.arange(B)
+    if packed.unsorted_indices is not None:
+        fin = fin_sorted[packed.unsorted_indices.cpu()]
+    else:
+        fin = fin_sorted
+    return fin.to(device)
+
+
+class StackGRUEncoder(StackGRU):
+
+    def __init__(self, params):
+        super().__init__(params)
+        self.latent_dim = self.params['latent_dim']
+        self.hidden_to_mu = nn.Linear(self.rnn_cell_size, self.latent_dim)
+        self.hidden_to_logvar = nn.Linear(self.rnn_cell_size, self.latent_dim)
+
+    def encoder_train_step(self, packed: PackedSequence):
+        """-> (mu, logvar) [B, Z] in ORIGINAL sample order."""
+        _require_packed(packed)
+        dev = self.embedding.weight.device
+        B = int(packed.batch_sizes[0])
+        h0 = torch.zeros(self.n_layers, B, self.rnn_cell_size, dtype=torch.float32, device=dev)
+        htop = self._run_sequence(packed, h0)
+        hfin = _GatherRows.apply(htop, _final_row_index(packed, dev))
+        mu = linear(hfin, self.hidden_to_mu.weight, self.hidden_to_mu.bias)
+        logvar = linear(hfin, self.hidden_to_logvar.weight, self.hidden_to_logvar.bias)
+        return mu, logvar
+
+    forward = encoder_train_step
+
+
+class StackGRUDecoder(StackGRU):
+
+    def __init__(self, params):
+        super().__init__(params)
+        self.latent_dim = self.params['latent_dim']
+        self.latent_to_hidden = nn.Linear(self.latent_dim, self.rnn_cell_size)
+        self.output_layer = nn.Linear(self.rnn_cell_size, self.vocab_size)
+
+    def decoder_train_step(self, latent_z, packed_in: PackedSequence, packed_tgt: PackedSequence):
+        """latent_z [1 or L, B, Z] in ORIGINAL sample order -> mean CE over non-pad targets."""
+        _require_packed(packed_in)
+        _require_packed(packed_tgt)
+        dev = self.embedding.weight.device
+        L = self.n_layers
+        if latent_z.dim() == 2:
+            latent_z = latent_z.unsqueeze(0)
+        if latent_z.shape[0] not in (1, L):
+            raise ValueError('latent_z must be [1, B, Z] or [n_layers, B, Z]')
+        B = latent_z.shape[1]
+        if B != int(packed_in.batch_sizes[0]):
+            raise ValueError('latent batch does not match the packed batch')
+        sidx = packed_in.sorted_indices
+        hs = []
+        for l in range(latent_z.shape[0]):
+            zl = latent_z[l]
+            if sidx is not None:
+                zl = _GatherRows.apply(zl, sidx.to(dev))
+            hs.append(linear(zl, self.latent_to_hidden.weight, self.latent_to_hidden.bias))
+        h0 = torch.stack(hs * (L // len(hs)), dim=0)
+        htop = self._run_sequence(packed_in, h0)
+        logits = linear(htop, self.output_layer.weight, self.output_layer.bias)
+        tgt = packed_tgt.data.reshape(-1).to(device=dev, dtype=torch.int64).contiguous()
+        return _CrossEntropy.apply(logits, tgt, 0)
+
+    forward = decoder_train_step
+
+
+class TeacherVAE(nn.Module):
+
+    def __init__(self, encoder: StackGRUEncoder, decoder: StackGRUDecoder):
+        super().__init__()
+        self.encoder = encoder
+        self.decoder = decoder
+        self._last_kl = None
+
+    def encode(self, input_seq):
+        return self.encoder.encoder_train_step(input_seq)
+
+    def reparameterize(self, mu, logvar, eps: Optional[torch.Tensor] = None):
+        """z = eps * exp(0.5 logvar) + mu.  `eps` may be injected (parity tests);
+        otherwise it is drawn with torch.randn_like as upstream does.  The fused
+        kernel also yields the KL term, kept in `self.last_kl`."""
+        if eps is None:
+            eps = torch.randn_like(mu)
+        z, kl = _ReparamKL.apply(mu, logvar, eps.to(mu.device))
+        self._last_kl = kl
+        return z
+
+    @property
+    def last_kl(self):
+        return self._last_kl
+
+    def decode(self, latent_z, input_seq, target_seq):
+        return self.decoder.decoder_train_step(latent_z, input_seq, target_seq)
+
+    def forward(self, input_seq, decoder_seq, target_seq, eps=None):
+        mu, logvar = self.encode(input_seq)
+        z = self.reparameterize(mu, logvar, eps).unsqueeze(0)
+        return self.decode(z, decoder_seq, target_seq), mu, logvar
+
+    def save(self, path, *args, **kwargs):
+        torch.save(self.state_dict(), path, *args, **kwargs)
+
+    def load(self, path, *args, **kwargs):
+        self.load_state_dict(torch.load(path, *args, weights_only=True, **kwargs))

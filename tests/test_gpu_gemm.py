@@ -62,9 +62,22 @@ def test_gemm_reproducible_splitk():
     assert (c1.double() - ref).abs().max().item() <= 1e-5 * ref.abs().max().item()
 
 
+def test_gemm_unaligned_leading_dims():
+    # lda = 178 / ldb = 53 (not multiples of 4) take the scalar-load path
+    from paccmann_polymer_amd import ops
+    torch.manual_seed(3)
+    A = torch.randn(100, 178, device='cuda')
+    W = torch.randn(1536, 178, device='cuda')
+    ref = A.double() @ W.double().T
+    assert (ops.gemm(A, W, transB=True).double() - ref).abs().max().item() <= 2e-6 * 178 * 16
+    B = torch.randn(178, 53, device='cuda')
+    ref = A.double() @ B.double()
+    assert (ops.gemm(A, B).double() - ref).abs().max().item() <= 2e-6 * 178 * 16
+
+
 def test_gemm_errors():
     from paccmann_polymer_amd import ops
-    A = torch.zeros(8, 6, device='cuda')   # lda = 6: not a multiple of 4
-    B = torch.zeros(6, 8, device='cuda')
-    with pytest.raises(ops._C.PPKError):
+    A = torch.zeros(8, 6, device='cuda')
+    B = torch.zeros(7, 8, device='cuda')
+    with pytest.raises(ValueError):
         ops.gemm(A, B)

@@ -1,0 +1,142 @@
+"""GPU parity of the StackGRU VAE step (K1 sequence kernels + fp32-MFMA GEMMs,
+K2 cross-entropy, K3 reparameterise + KL) through the C-ABI against the CPU
+restatement oracle/stackgru_ref.py (torch nn.GRU / CrossEntropyLoss /
+pack_sequence primitives) on identical weights, tokens and injected eps.
+
+Parity versus upstream paccmann_chemistry itself is UNPINNED (package absent
+offline); the GRU cell / CE arithmetic is pinned to torch's.
+Bars: loss 1e-5 rel, gradients 1e-4 rel (north_star)."""
+import numpy as np
+import pytest
+import torch
+from torch.nn.utils.rnn import pack_sequence
+
+pytestmark = pytest.mark.gpu
+
+SMALL = dict(vocab_size=20, embedding_size=16, rnn_cell_size=32, n_layers=2, stack_width=6, stack_depth=5,
+             latent_dim=8, dropout=0.0, padding_index=0, batch_size=1, batch_mode='packed')
+ODD = dict(vocab_size=33, embedding_size=10, rnn_cell_size=20, n_layers=3, stack_width=7, stack_depth=4,
+           latent_dim=5, dropout=0.0, padding_index=0, batch_size=1, batch_mode='packed')
+FULL = dict(vocab_size=64, embedding_size=128, rnn_cell_size=512, n_layers=2, stack_width=50, stack_depth=50,
+            latent_dim=256, dropout=0.0, padding_index=0, batch_size=1, batch_mode='packed')
+
+
+def make_batch(rng, B, vocab, lo, hi):
+    seqs = []
+    for _ in range(B):
+        n = int(rng.integers(lo, hi + 1))
+        body = rng.integers(4, vocab, size=n - 2)
+        seqs.append(torch.tensor(np.concatenate([[2], body, [3]]), dtype=torch.int64))
+    return seqs
+
+
+def prep(seqs):
+    enc = pack_sequence(seqs, enforce_sorted=False)
+    tgt = pack_sequence([torch.cat([s[1:], torch.tensor([0])]) for s in seqs], enforce_sorted=False)
+    return enc, enc, tgt
+
+
+def rel(a, b):
+    a = a.detach().double().cpu().reshape(-1)
+    b = b.detach().double().cpu().reshape(-1)
+    return float((a - b).norm() / max(float(b.norm()), 1e-30))
+
+
+def build_pair(params, seed, dtype):
+    from oracle import stackgru_ref as R
+    from paccmann_polymer_amd import stack_gru_vae as M
+    torch.manual_seed(seed)
+    ref = R.TeacherVAERef(R.StackGRUEncoderRef(params), R.StackGRUDecoderRef(params)).to(dtype)
+    gpu = M.TeacherVAE(M.StackGRUEncoder(params), M.StackGRUDecoder(params))
+    gpu.load_state_dict({k: v.float() for k, v in ref.state_dict().items()})
+    return ref, gpu.cuda()
+
+
+@pytest.mark.parametrize('params,B,lo,hi,seed', [
+    (SMALL, 5, 3, 9, 0), (SMALL, 1, 4, 4, 1), (ODD, 7, 3, 12, 2), (SMALL, 9, 5, 5, 3), (FULL, 16, 5, 30, 4),
+])
+def test_train_step_matches_oracle_fp64(params, B, lo, hi, seed):
+    from oracle import stackgru_ref as R
+    rng = np.random.default_rng(seed)
+    ref, gpu = build_pair(params, seed, torch.float64)
+    seqs = make_batch(rng, B, params['vocab_size'], lo, hi)
+    enc, dec, tgt = prep(seqs)
+    eps = torch.tensor(rng.standard_normal((B, params['latent_dim'])), dtype=torch.float64)
+
+    loss_r, mu_r, lv_r, z_r = R.train_step_ref(ref, enc, dec, tgt, eps)
+    kl_r = R.kl_divergence(mu_r, lv_r)
+    (loss_r + 0.3 * kl_r + 0.1 * z_r.pow(2).sum()).backward()
+
+    mu, lv = gpu.encode(enc)
+    z = gpu.reparameterize(mu, lv, eps.float().cuda()).unsqueeze(0)
+    loss = gpu.decode(z, dec, tgt)
+    (loss + 0.3 * gpu.last_kl + 0.1 * z.pow(2).sum()).backward()
+
+    assert abs(float(loss) - float(loss_r)) <= 1e-5 * abs(float(loss_r))
+    assert abs(float(gpu.last_kl) - float(kl_r)) <= 1e-5 * abs(float(kl_r))
+    assert rel(mu, mu_r) <= 1e-5 and rel(lv, lv_r) <= 1e-5 and rel(z, z_r) <= 1e-5
+    refg = dict(ref.named_parameters())
+    worst = 0.0
+    for name, p in gpu.named_parameters():
+        g_r = refg[name].grad
+        assert p.grad is not None, name
+        if float(g_r.norm()) < 1e-12:
+            assert float(p.grad.norm()) < 1e-9, name
+            continue
+        worst = max(worst, rel(p.grad, g_r))
+        assert rel(p.grad, g_r) <= 1e-4, (name, rel(p.grad, g_r))
+    # padding row of the embedding has no gradient
+    assert float(gpu.encoder.embedding.weight.grad[0].abs().max()) == 0.0
+
+
+def test_bitwise_reproducible():
+    rng = np.random.default_rng(11)
+    _, gpu = build_pair(SMALL, 11, torch.float64)
+    seqs = make_batch(rng, 6, SMALL['vocab_size'], 3, 10)
+    enc, dec, tgt = prep(seqs)
+    eps = torch.randn(6, SMALL['latent_dim']).cuda()
+    outs = []
+    for _ in range(2):
+        gpu.zero_grad(set_to_none=True)
+        mu, lv = gpu.encode(enc)
+        z = gpu.reparameterize(mu, lv, eps).unsqueeze(0)
+        loss = gpu.decode(z, dec, tgt)
+        loss.backward()
+        outs.append([loss.detach().clone()] + [p.grad.clone() for p in gpu.parameters()])
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+
+
+def test_kernels_vs_torch_fp32_small_ops():
+    """K2 / K3 in isolation against plain torch fp32 on the GPU."""
+    from paccmann_polymer_amd import stack_gru_vae as M
+    torch.manual_seed(0)
+    logits = torch.randn(301, 37, device='cuda', requires_grad=True)
+    tgt = torch.randint(0, 37, (301,), device='cuda')
+    loss = M._CrossEntropy.apply(logits, tgt, 0)
+    loss.backward()
+    l2 = logits.detach().clone().requires_grad_(True)
+    ref = torch.nn.functional.cross_entropy(l2, tgt, ignore_index=0)
+    ref.backward()
+    assert abs(float(loss) - float(ref)) <= 1e-6 * abs(float(ref))
+    assert rel(logits.grad, l2.grad) <= 1e-5
+    mu = torch.randn(40, 9, device='cuda', requires_grad=True)
+    lv = torch.randn(40, 9, device='cuda', requires_grad=True)
+    eps = torch.randn(40, 9, device='cuda')
+    z, kl = M.reparameterize_kl(mu, lv, eps)
+    (z.sum() * 0.7 + 2.0 * kl).backward()
+    mu2, lv2 = mu.detach().clone().requires_grad_(True), lv.detach().clone().requires_grad_(True)
+    z2 = eps * torch.exp(0.5 * lv2) + mu2
+    kl2 = -0.5 * torch.sum(1 + lv2 - mu2.pow(2) - lv2.exp())
+    (z2.sum() * 0.7 + 2.0 * kl2).backward()
+    assert rel(z, z2) <= 1e-6 and abs(float(kl) - float(kl2)) <= 1e-5 * abs(float(kl2))
+    assert rel(mu.grad, mu2.grad) <= 1e-5 and rel(lv.grad, lv2.grad) <= 1e-5
+
+
+def test_rejects_cpu_and_unpacked():
+    from paccmann_polymer_amd import stack_gru_vae as M
+    enc = M.StackGRUEncoder(SMALL).cuda()
+    with pytest.raises(TypeError):
+        enc.encoder_train_step(torch.zeros(4, 2, dtype=torch.int64))
+    with pytest.raises(IndexError):
+        enc.encoder_train_step(pack_sequence([torch.tensor([2, 99, 3])]))

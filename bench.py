@@ -1,0 +1,208 @@
+"""Benchmark of the graph-regularised SMILES-VAE training step (BASELINE.json
+configs[1]): batch 2048 per GPU (128 bundles x 16 SMILES, len 20..100), fp32,
+StackGRU VAE (vocab 64, E 128, H 512, L 2, stack 50x50, Z 256), graph_gamma 1,
+Adam lr 1e-4.  One "step" = encoder + reparameterise + decoder + graph loss,
+forward and backward, + optimizer, inputs resident in HBM.
+
+    python bench.py --gpus N --steps K --warmup W
+(N > 1: launched by torch.distributed.run, one rank per GPU over RCCL; weak scaling.)
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+from torch.nn.utils.rnn import PackedSequence, pack_sequence
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PARAMS = dict(vocab_size=64, embedding_size=128, rnn_cell_size=512, n_layers=2, stack_width=50, stack_depth=50,
+              latent_dim=256, dropout=0.0, bidirectional=False, use_stack=True, batch_mode='packed',
+              padding_index=0, batch_size=1)
+PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+PEAK_HBM_GBS = 8000.0
+
+
+def synth_batch(rng, n_bundles, bundle_nodes, lo=20, hi=100, vocab=64):
+    """Synthetic SMILES token lists + per-bundle relation graphs (random tree + a few chords, <= 20 edges)."""
+    from paccmann_polymer_amd.data_prep import hop_distance_matrix
+    seqs, gs, sizes = [], [], []
+    for _ in range(n_bundles):
+        n = bundle_nodes
+        edges = [[int(rng.integers(0, v)), v] for v in range(1, n)]
+        for _ in range(min(4, max(0, 20 - (n - 1)))):
+            a, b = rng.integers(0, n, size=2)
+            if a != b:
+                edges.append([int(a), int(b)])
+        ei = np.asarray(edges, dtype=np.int64).T
+        gs.append(hop_distance_matrix(ei, n, order='networkx'))
+        sizes.append(n)
+        for _ in range(n):
+            L = int(rng.integers(lo, hi + 1))
+            seqs.append(torch.tensor(np.concatenate([[2], rng.integers(4, vocab, size=L - 2), [3]]), dtype=torch.int64))
+    return seqs, gs, sizes
+
+
+def to_device_batch(seqs, gs, device):
+    enc = pack_sequence(seqs, enforce_sorted=False)
+    tgt = pack_sequence([torch.cat([s[1:], torch.zeros(1, dtype=torch.int64)]) for s in seqs], enforce_sorted=False)
+
+    def dev(p):
+        return PackedSequence(p.data.to(device), p.batch_sizes, p.sorted_indices.to(device), p.unsorted_indices.to(device))
+    g_flat = torch.tensor(np.concatenate([g.ravel() for g in gs]), dtype=torch.float64, device=device)
+    return dev(enc), dev(enc), dev(tgt), g_flat
+
+
+def cpu_baseline(seed=0, n_bundles=4, bundle_nodes=16):
+    """Reference-semantics CPU step (the oracle: per-timestep nn.GRU StackGRU VAE + loop-for-loop
+    graph_loss in C + analytic gradient) on a bounded sample: config 1b, batch 64 = 4 bundles x 16."""
+    from oracle import stackgru_ref as R
+    from oracle import graph_loss_oracle as O
+    rng = np.random.default_rng(seed)
+    torch.manual_seed(seed)
+    seqs, gs, sizes = synth_batch(rng, n_bundles, bundle_nodes)
+    vae = R.TeacherVAERef(R.StackGRUEncoderRef(PARAMS), R.StackGRUDecoderRef(PARAMS))
+    opt = torch.optim.Adam(vae.parameters(), lr=1e-4)
+    enc = pack_sequence(seqs, enforce_sorted=False)
+    tgt = pack_sequence([torch.cat([s[1:], torch.zeros(1, dtype=torch.int64)]) for s in seqs], enforce_sorted=False)
+    B = len(seqs)
+    eps = torch.randn(B, PARAMS['latent_dim'])
+
+    def step():
+        opt.zero_grad()
+        dec_loss, mu, logvar, z = R.train_step_ref(vae, enc, enc, tgt, eps)
+        z2 = z.squeeze(0)
+        gl, dz = O.graph_loss_segmented_c(z2.detach().numpy(), gs, sizes, acc_fp32=True)
+        # graph_gamma = 1: inject the oracle's analytic d(graph_loss)/dz
+        (dec_loss + (z2 * torch.tensor(dz, dtype=torch.float32)).sum()).backward()
+        opt.step()
+    step()                      # warm-up
+    t0 = time.perf_counter()
+    n = 0
+    while time.perf_counter() - t0 < 12.0 and n < 8:
+        step()
+        n += 1
+    dt = (time.perf_counter() - t0) / n
+    return dict(value=B / dt, unit='samples/s', cores=torch.get_num_threads(), kind='port',
+                sample=f'config 1b: batch {B} = {n_bundles} bundles x {bundle_nodes} SMILES (len 20..100), '
+                       f'{n} full steps (fwd+bwd+Adam) of the oracle (torch nn.GRU per timestep + C graph_loss loop), '
+                       f'{dt:.2f} s/step')
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=5)
+    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--bundles', type=int, default=128)
+    ap.add_argument('--bundle-nodes', type=int, default=16)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+    torch.cuda.set_device(local_rank)
+    device = torch.device('cuda', local_rank)
+
+    import paccmann_polymer_amd as P
+    from paccmann_polymer_amd.paccmann_encoder import Encoder
+    from paccmann_polymer_amd.optim import FlatAdam
+    from paccmann_polymer_amd.distributed import GradSync, global_token_count, dp_train_step
+    from paccmann_polymer_amd.graph_constrained_loss import graph_loss_segmented
+
+    torch.manual_seed(0)                                  # identical weights on every rank
+    model = Encoder(PARAMS, None, None, batch_size=1, batch_mode='Packed')
+    model.gru_vae.train()
+    opt = FlatAdam(model.gru_vae.parameters(), lr=1e-4)
+    rng = np.random.default_rng(1234 + rank)              # a different shard per rank (weak scaling)
+    seqs, gs, sizes = synth_batch(rng, args.bundles, args.bundle_nodes)
+    enc, dec, tgt, g_flat = to_device_batch(seqs, gs, device)
+    B = len(seqs)
+    model.update_batch_size(B)
+    eps = torch.randn(B, PARAMS['latent_dim'], device=device)
+    n_tokens = int(enc.data.numel())
+    local_valid = n_tokens - B
+    total_valid = global_token_count(local_valid)
+    sync = GradSync(opt.flat_grad)
+
+    def fwd():
+        dec_loss, mu, logvar, z = model.train_step(enc, dec, tgt, eps)
+        return dec_loss, graph_loss_segmented(z.squeeze(0), g_flat, sizes)
+
+    def step():
+        return dp_train_step(fwd, opt, local_valid, total_valid, 1.0, sync)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss, dl, gl = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    ms_per_step = dt / args.steps * 1e3
+
+    # ---- roofline of the dominant kernel: one extra step with per-launch HIP events on the launch stream
+    lib = P._C.lib
+    nk = lib.ppk_prof_kind_count()
+    lib.ppk_prof_enable(1)
+    step()
+    torch.cuda.synchronize()
+    lib.ppk_prof_enable(0)
+    ms = (ctypes.c_double * nk)()
+    work = (ctypes.c_double * nk)()
+    launches = (ctypes.c_int64 * nk)()
+    lib.ppk_prof_collect(ms, work, launches)
+    kinds = [dict(kernel=lib.ppk_prof_kind_name(k).decode(), ms=ms[k], work=work[k], launches=int(launches[k]))
+             for k in range(nk) if launches[k]]
+    kinds.sort(key=lambda d: -d['ms'])
+    top = kinds[0]
+    is_gemm = top['kernel'].startswith('k_gemm')
+    achieved = top['work'] / (top['ms'] * 1e-3) / (1e12 if is_gemm else 1e9)
+    peak = PEAK_FP32_MFMA_TFLOPS if is_gemm else PEAK_HBM_GBS
+    roofline = dict(bound='mfma' if is_gemm else 'hbm', achieved=round(achieved, 2), peak=peak,
+                    unit='TFLOP/s' if is_gemm else 'GB/s', frac=round(achieved / peak, 4), traffic=None,
+                    kernel=top['kernel'], launches_per_step=top['launches'],
+                    avg_launch_us=round(top['ms'] * 1e3 / top['launches'], 2),
+                    step_breakdown_ms={d['kernel']: round(d['ms'], 3) for d in kinds})
+
+    out = dict(metric='training samples/sec (whole node)', value=round(B * world / (dt / args.steps), 1),
+               unit='samples/s', n_gpus=world, steps=args.steps, warmup=args.warmup,
+               ms_per_step=round(ms_per_step, 3), higher_is_better=True, scaling='weak', vs_baseline=None,
+               dtype='f32', data='synthetic',
+               config=dict(workload=f'configs[1]: graph-regularised SMILES-VAE step, batch {B}/GPU = {args.bundles} bundles x '
+                                    f'{args.bundle_nodes} SMILES (len 20..100), StackGRU VAE V64 E128 H512 L2 stack50x50 Z256, '
+                                    f'graph_gamma 1, Adam lr 1e-4, fp32', global_batch=B * world,
+                           tokens_per_gpu=n_tokens, parallelism=f'dp{world}'),
+               roofline=roofline, final_loss=float(loss))
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out['cpu_baseline'] = cpu_baseline()
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -47,6 +47,15 @@ const char* ppk_version(void);
 const char* ppk_last_error(void);
 int         ppk_device_count(void);
 
+/* Opt-in per-kernel-family timing with HIP events on the launch stream (no
+ * reference counterpart; bench.py uses it for the roofline figures).  Process-wide,
+ * not thread-safe; off by default.  ppk_prof_collect synchronises the recorded
+ * events and fills three arrays of ppk_prof_kind_count() entries. */
+int         ppk_prof_enable(int on);
+int         ppk_prof_kind_count(void);
+const char* ppk_prof_kind_name(int kind);
+int         ppk_prof_collect(double* ms, double* work, int64_t* launches);
+
 /* ---- K4: dense graph-regularisation loss --------------------------------
  * Replaces graph_loss / compute_graph_dists / graph_regularizer_function,
  *   paccmann_polymer/topologically_regularized_models/graph_constrained_loss.py:4-67
@@ -118,11 +127,14 @@ int ppk_stackgru_seq_fwd(int64_t T, const int64_t* batch_sizes_host, int64_t B, 
 /* dHtop [NT, H] = gradient at the top layer's output of every step.  Outputs:
  * dX [NT, ldx], DGI / DGH [L, NT, 3H] (gate pre-activation gradients of the
  * input / hidden side), DCS [NT, ldcs], dh0 [L, B, H].  Weight gradients are
- * single GEMMs over these: dW_ih = DGI^T In, dW_hh = DGH^T HP, dWcs = DCS^T HP[L-1]. */
+ * single GEMMs over these: dW_ih = DGI^T In, dW_hh = DGH^T HP, dWcs = DCS^T HP[L-1].
+ * The backward takes the weights TRANSPOSED (host arrays of L device pointers
+ * w_ih_t[l] [I_l, 3H], w_hh_t[l] [H, 3H]; wcs_t [H, ldcs]) so that the per-step
+ * data-gradient GEMMs read k-contiguous operands. */
 size_t ppk_stackgru_seq_bwd_workspace_bytes(int64_t B, int64_t H, int64_t W, int64_t D);
 int ppk_stackgru_seq_bwd(int64_t T, const int64_t* batch_sizes_host, int64_t B, int64_t NT,
                          int64_t V, int64_t E, int64_t H, int64_t L, int64_t W, int64_t D,
-                         const float* const* w_ih, int64_t ld_wih0, const float* const* w_hh, const float* wcs,
+                         const float* const* w_ih_t, const float* const* w_hh_t, const float* wcs_t,
                          const float* HP, const float* gates, const float* S, const float* CS, int64_t ldcs,
                          const float* dHtop, float* dX, int64_t ldx, float* DGI, float* DGH, float* DCS,
                          float* dh0, void* workspace, size_t ws_bytes, ppk_stream_t stream);

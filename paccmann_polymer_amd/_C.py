@@ -28,6 +28,10 @@ SIGNATURES = {
     'ppk_version': (ctypes.c_char_p, []),
     'ppk_last_error': (ctypes.c_char_p, []),
     'ppk_device_count': (c_int, []),
+    'ppk_prof_enable': (c_int, [c_int]),
+    'ppk_prof_kind_count': (c_int, []),
+    'ppk_prof_kind_name': (ctypes.c_char_p, [c_int]),
+    'ppk_prof_collect': (c_int, [ptr, ptr, ptr]),
     'ppk_graphreg_dense_workspace_bytes': (c_sz, [c_i64, c_i64, c_i64]),
     'ppk_graphreg_dense_fwd': (c_int, [ptr, c_i64, ptr, c_int, ptr, ptr,
                                        c_i64, c_i64, c_i64, c_i64, c_i64,
@@ -44,7 +48,7 @@ SIGNATURES = {
                                      ptr, c_i64, ptr, ptr, ptr, ptr, ptr, c_i64, ptr, c_sz, ptr]),
     'ppk_stackgru_seq_bwd_workspace_bytes': (c_sz, [c_i64, c_i64, c_i64, c_i64]),
     'ppk_stackgru_seq_bwd': (c_int, [c_i64, ptr, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64,
-                                     ptr, c_i64, ptr, ptr, ptr, ptr, ptr, ptr, c_i64,
+                                     ptr, ptr, ptr, ptr, ptr, ptr, ptr, c_i64,
                                      ptr, ptr, c_i64, ptr, ptr, ptr, ptr, ptr, c_sz, ptr]),
     'ppk_gather_rows': (c_int, [ptr, c_i64, c_i64, ptr, c_i64, c_i64, ptr, c_i64, ptr]),
     'ppk_scatter_rows': (c_int, [ptr, c_i64, ptr, c_i64, c_i64, ptr, c_i64, c_i64, ptr]),

@@ -1,6 +1,8 @@
 // Library-level entry points: version, last-error string, device probe.
 #include "ppk_common.h"
+#include "ppk_kernels.h"
 #include <stdarg.h>
+#include <vector>
 
 static thread_local char g_err[512] = "";
 
@@ -30,6 +32,71 @@ int ppk_device_count(void)
         return PPK_ERR_HIP;
     }
     return n;
+}
+
+}  // extern "C"
+
+// ---------------------------------------------------------------- profiling
+namespace {
+struct ProfRec { hipEvent_t a, b; double work; int kind; };
+bool g_prof_on = false;
+std::vector<ProfRec> g_prof;
+const char* const kKindNames[ppk::PK_COUNT] = {
+    "k_gemm<64,64,XX>", "k_gemm<64,64,XK>", "k_gemm<64,64,KX>", "k_gemm<64,64,KK>",
+    "k_gemm<128,128,XX>", "k_gemm<128,128,XK>", "k_gemm<128,128,KX>", "k_gemm<128,128,KK>",
+    "k_stack_fwd", "k_stack_bwd", "k_gate_fwd", "k_gate_bwd",
+    "k_terms", "k_dz", "k_spmm", "k_graphreg_sparse",
+};
+}  // namespace
+
+namespace ppk {
+ProfScope::ProfScope(int kind, double work, hipStream_t s) : idx(-1), stream(s)
+{
+    if (!g_prof_on) return;
+    ProfRec r;
+    r.work = work;
+    r.kind = kind;
+    if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return;
+    (void)hipEventRecord(r.a, s);
+    g_prof.push_back(r);
+    idx = (int)g_prof.size() - 1;
+}
+ProfScope::~ProfScope()
+{
+    if (idx >= 0) (void)hipEventRecord(g_prof[(size_t)idx].b, stream);
+}
+}  // namespace ppk
+
+extern "C" {
+
+int ppk_prof_enable(int on)
+{
+    g_prof_on = on != 0;
+    return PPK_OK;
+}
+
+int ppk_prof_kind_count(void) { return ppk::PK_COUNT; }
+
+const char* ppk_prof_kind_name(int kind) { return (kind >= 0 && kind < ppk::PK_COUNT) ? kKindNames[kind] : ""; }
+
+// Waits for the recorded events, sums per kind (ms, work, launches; arrays of
+// ppk_prof_kind_count() entries), then clears the records.
+int ppk_prof_collect(double* ms, double* work, int64_t* launches)
+{
+    if (!ms || !work || !launches) PPK_FAIL(PPK_ERR_NULL, "prof_collect: null pointer");
+    for (int k = 0; k < ppk::PK_COUNT; ++k) { ms[k] = 0; work[k] = 0; launches[k] = 0; }
+    for (ProfRec& r : g_prof) {
+        float t = 0.f;
+        if (hipEventSynchronize(r.b) == hipSuccess && hipEventElapsedTime(&t, r.a, r.b) == hipSuccess) {
+            ms[r.kind] += t;
+            work[r.kind] += r.work;
+            launches[r.kind] += 1;
+        }
+        (void)hipEventDestroy(r.a);
+        (void)hipEventDestroy(r.b);
+    }
+    g_prof.clear();
+    return PPK_OK;
 }
 
 }  // extern "C"

@@ -18,6 +18,7 @@
 // sums in slice order (bitwise reproducible, no atomics).
 #include "ppk_common.h"
 #include "ppk_kernels.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -122,25 +123,30 @@ struct GemmArgs {
     long long lda, ldb, ldc;
     int M, N, K;
     float alpha, beta;
-    int ksplit;          // number of K slices (grid.z)
+    int ksplit;          // number of K slices (grid.z) — single-problem launches only
     int kslice;          // K elements per slice (multiple of BK)
     float* slabs;        // [ksplit][M][N] when ksplit > 1
     int a_vec, b_vec;    // operand base 16-B aligned and leading dimension % 4 == 0 -> float4 loads
 };
+// up to two independent problems per launch (grid.z picks the problem): the two
+// gate GEMMs of a GRU layer-step share one launch so the grid fills the chip.
+struct GemmBatch { GemmArgs p[2]; int grouped; };
 
 template <int BM, int BN, bool A_KC, bool B_KC>
-__global__ __launch_bounds__(256) void k_gemm(const GemmArgs g)
+__global__ __launch_bounds__(256) void k_gemm(const GemmBatch gb)
 {
     constexpr int TM = BM / 64, TN = BN / 64;       // 32x32 tiles per wave
     __shared__ __align__(16) float lds[lds_floats<BM, A_KC>() + lds_floats<BN, B_KC>()];
     float* ldsA = lds;
     float* ldsB = lds + lds_floats<BM, A_KC>();
 
+    const GemmArgs& g = gb.p[gb.grouped ? blockIdx.z : 0];
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    if (m0 >= g.M || n0 >= g.N) return;             // grouped launch: grid is the max over problems
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int li = lane & 31, h = lane >> 5;
-    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
-    const int kbeg = blockIdx.z * g.kslice;
+    const int kbeg = gb.grouped ? 0 : blockIdx.z * g.kslice;
     const int kend = min(g.K, kbeg + g.kslice);
 
     f32x16 acc[TM][TN];
@@ -223,44 +229,57 @@ __global__ __launch_bounds__(256) void k_gemm_reduce(const GemmArgs g)
     }
 }
 
-template <int BM, int BN>
-void launch(const GemmArgs& g, bool a_kc, bool b_kc, hipStream_t stream)
-{
-    dim3 grid((g.N + BN - 1) / BN, (g.M + BM - 1) / BM, g.ksplit), block(256);
-    if (a_kc && b_kc)        k_gemm<BM, BN, true, true><<<grid, block, 0, stream>>>(g);
-    else if (a_kc && !b_kc)  k_gemm<BM, BN, true, false><<<grid, block, 0, stream>>>(g);
-    else if (!a_kc && b_kc)  k_gemm<BM, BN, false, true><<<grid, block, 0, stream>>>(g);
-    else                     k_gemm<BM, BN, false, false><<<grid, block, 0, stream>>>(g);
-}
-
 inline long long cdiv(long long a, long long b) { return (a + b - 1) / b; }
 
-}  // namespace
-
-namespace ppk {
-
-size_t gemm_workspace_bytes(int64_t M, int64_t N, int64_t K)
+template <int BM, int BN>
+void launch(const GemmBatch& gb, int count, bool a_kc, bool b_kc, hipStream_t stream)
 {
-    // room for up to 16 K-slabs
-    (void)K;
-    return ppk_align_up(sizeof(float) * (size_t)M * (size_t)N * 16, 256);
+    long long gx = 0, gy = 0;
+    for (int i = 0; i < count; ++i) {
+        gx = gx > cdiv(gb.p[i].N, BN) ? gx : cdiv(gb.p[i].N, BN);
+        gy = gy > cdiv(gb.p[i].M, BM) ? gy : cdiv(gb.p[i].M, BM);
+    }
+    dim3 grid((unsigned)gx, (unsigned)gy, gb.grouped ? count : gb.p[0].ksplit), block(256);
+    if (a_kc && b_kc)        k_gemm<BM, BN, true, true><<<grid, block, 0, stream>>>(gb);
+    else if (a_kc && !b_kc)  k_gemm<BM, BN, true, false><<<grid, block, 0, stream>>>(gb);
+    else if (!a_kc && b_kc)  k_gemm<BM, BN, false, true><<<grid, block, 0, stream>>>(gb);
+    else                     k_gemm<BM, BN, false, false><<<grid, block, 0, stream>>>(gb);
 }
 
-int gemm(int transA, int transB, int64_t M, int64_t N, int64_t K, float alpha,
-         const float* A, int64_t lda, const float* B, int64_t ldb, float beta,
-         float* C, int64_t ldc, const float* bias, void* ws, size_t ws_bytes, hipStream_t stream)
-{
-    if (M < 0 || N < 0 || K < 0) PPK_FAIL(PPK_ERR_SHAPE, "gemm: negative size");
-    if (M == 0 || N == 0) return PPK_OK;
-    if (!A || !B || !C) PPK_FAIL(PPK_ERR_NULL, "gemm: null operand");
-    if (M > 0x7fffffff || N > 0x7fffffff || K > 0x7fffffff) PPK_FAIL(PPK_ERR_UNSUP, "gemm: dimension >= 2^31");
-    const bool a_kc = !transA, b_kc = transB != 0;
-    if (lda < (a_kc ? K : M) || ldb < (b_kc ? K : N) || ldc < N)
-        PPK_FAIL(PPK_ERR_SHAPE, "gemm: leading dimension too small (lda=%lld ldb=%lld ldc=%lld)", (long long)lda, (long long)ldb, (long long)ldc);
-    if (((uintptr_t)A & 3) || ((uintptr_t)B & 3) || ((uintptr_t)C & 3))
-        PPK_FAIL(PPK_ERR_ALIGN, "gemm: operands must be 4-byte aligned");
+// tile: 0 = 64x64, 1 = 128x64, 2 = 128x128 ; ksplit >= 1
+struct Plan { int tile; int ksplit; };
 
-    GemmArgs g;
+// Measured on MI355X (tools/bench_gemm.py): the per-step shapes (M <= 2048, K <= 1536)
+// are latency-bound and run best on 64x64 tiles at >= 3 blocks/CU; long-K
+// contractions (weight gradients, K = sum of sequence lengths) want 128-row tiles
+// plus enough K slices to put >= 2 blocks on every CU.
+Plan make_plan(long long M, long long N, long long K, bool allow_split)
+{
+    Plan pl{0, 1};
+    int ov = 0;
+    if (const char* e = getenv("PPK_GEMM_TILE")) ov = atoi(e);       // tuning aid: 1 / 2 / 3 force 64x64 / 128x128 / 128x64
+    const long long b22 = cdiv(M, 128) * cdiv(N, 128), b21 = cdiv(M, 128) * cdiv(N, 64), b11 = cdiv(M, 64) * cdiv(N, 64);
+    if (ov == 1) pl.tile = 0;
+    else if (ov == 2) pl.tile = 2;
+    else if (ov == 3) pl.tile = 1;
+    else if (K >= 8192) pl.tile = N > 192 ? 2 : 1;
+    else if (b22 >= 768) pl.tile = 2;
+    else if (b21 >= 768) pl.tile = 1;
+    else pl.tile = 0;
+    const long long blocks = pl.tile == 2 ? b22 : (pl.tile == 1 ? b21 : b11);
+    if (allow_split && blocks < 256 && K >= 2048) {
+        long long want = cdiv(512, blocks);
+        long long maxs = K / 1024;
+        long long s = want < maxs ? want : maxs;
+        if (s > 64) s = 64;
+        if (s > 1) pl.ksplit = (int)s;
+    }
+    return pl;
+}
+
+void fill_args(GemmArgs& g, int64_t M, int64_t N, int64_t K, float alpha, const float* A, int64_t lda,
+               const float* B, int64_t ldb, float beta, float* C, int64_t ldc, const float* bias)
+{
     g.A = A; g.B = B; g.C = C; g.bias = bias;
     g.lda = lda; g.ldb = ldb; g.ldc = ldc;
     g.M = (int)M; g.N = (int)N; g.K = (int)K;
@@ -268,26 +287,64 @@ int gemm(int transA, int transB, int64_t M, int64_t N, int64_t K, float alpha,
     g.a_vec = !(lda & 3) && !((uintptr_t)A & 15);
     g.b_vec = !(ldb & 3) && !((uintptr_t)B & 15);
     g.ksplit = 1; g.kslice = (int)(cdiv(K > 0 ? K : 1, BK) * BK); g.slabs = nullptr;
+}
 
-    // tile choice: 128x128 when it fills the chip, else 64x64
-    const long long big = cdiv(M, 128) * cdiv(N, 128), small = cdiv(M, 64) * cdiv(N, 64);
-    const bool use_big = big >= 200;
-    const long long blocks = use_big ? big : small;
-    if (blocks < 128 && K >= 2048 && ws) {
-        long long want = 512 / blocks;                       // aim at ~2 blocks per CU
-        long long maxs = K / 512;                            // keep >= 512 of K per slice
-        long long s = want < maxs ? want : maxs;
-        if (s > 16) s = 16;
-        const size_t need = sizeof(float) * (size_t)M * (size_t)N * (size_t)(s > 1 ? s : 0);
-        if (s > 1 && need <= ws_bytes) {
-            g.ksplit = (int)s;
-            g.kslice = (int)(cdiv(cdiv(K, s), BK) * BK);
+int check_problem(int transA, int transB, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda,
+                  const float* B, int64_t ldb, const float* C, int64_t ldc)
+{
+    if (M < 0 || N < 0 || K < 0) PPK_FAIL(PPK_ERR_SHAPE, "gemm: negative size");
+    if (!A || !B || !C) PPK_FAIL(PPK_ERR_NULL, "gemm: null operand");
+    if (M > 0x7fffffff || N > 0x7fffffff || K > 0x7fffffff) PPK_FAIL(PPK_ERR_UNSUP, "gemm: dimension >= 2^31");
+    const bool a_kc = !transA, b_kc = transB != 0;
+    if (lda < (a_kc ? K : M) || ldb < (b_kc ? K : N) || ldc < N)
+        PPK_FAIL(PPK_ERR_SHAPE, "gemm: leading dimension too small (lda=%lld ldb=%lld ldc=%lld)", (long long)lda, (long long)ldb, (long long)ldc);
+    if (((uintptr_t)A & 3) || ((uintptr_t)B & 3) || ((uintptr_t)C & 3))
+        PPK_FAIL(PPK_ERR_ALIGN, "gemm: operands must be 4-byte aligned");
+    return PPK_OK;
+}
+
+void dispatch(const GemmBatch& gb, int count, int tile, bool a_kc, bool b_kc, double flops, hipStream_t stream)
+{
+    ppk::ProfScope prof((tile ? 4 : 0) + (a_kc ? 2 : 0) + (b_kc ? 1 : 0), flops, stream);
+    if (tile == 2)      launch<128, 128>(gb, count, a_kc, b_kc, stream);
+    else if (tile == 1) launch<128, 64>(gb, count, a_kc, b_kc, stream);
+    else                launch<64, 64>(gb, count, a_kc, b_kc, stream);
+}
+
+}  // namespace
+
+namespace ppk {
+
+size_t gemm_workspace_bytes(int64_t M, int64_t N, int64_t K)
+{
+    if (M <= 0 || N <= 0) return 0;
+    const Plan pl = make_plan(M, N, K, true);
+    return pl.ksplit > 1 ? ppk_align_up(sizeof(float) * (size_t)M * (size_t)N * (size_t)pl.ksplit, 256) : 0;
+}
+
+int gemm(int transA, int transB, int64_t M, int64_t N, int64_t K, float alpha,
+         const float* A, int64_t lda, const float* B, int64_t ldb, float beta,
+         float* C, int64_t ldc, const float* bias, void* ws, size_t ws_bytes, hipStream_t stream)
+{
+    if (M == 0 || N == 0) return PPK_OK;
+    int rc = check_problem(transA, transB, M, N, K, A, lda, B, ldb, C, ldc);
+    if (rc) return rc;
+    const bool a_kc = !transA, b_kc = transB != 0;
+    GemmBatch gb;
+    gb.grouped = 0;
+    GemmArgs& g = gb.p[0];
+    fill_args(g, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, bias);
+    gb.p[1] = g;
+    Plan pl = make_plan(M, N, K, ws != nullptr);
+    if (pl.ksplit > 1) {
+        const size_t need = sizeof(float) * (size_t)M * (size_t)N * (size_t)pl.ksplit;
+        if (need <= ws_bytes) {
+            g.kslice = (int)(cdiv(cdiv(K, pl.ksplit), BK) * BK);
             g.ksplit = (int)cdiv(K, g.kslice);
             g.slabs = (float*)ws;
         }
     }
-    if (use_big) launch<128, 128>(g, a_kc, b_kc, stream);
-    else         launch<64, 64>(g, a_kc, b_kc, stream);
+    dispatch(gb, 1, pl.tile, a_kc, b_kc, 2.0 * (double)M * (double)N * (double)K, stream);
     PPK_CHECK_LAUNCH("k_gemm");
     if (g.ksplit > 1) {
         long long total = (long long)M * N;
@@ -298,13 +355,35 @@ int gemm(int transA, int transB, int64_t M, int64_t N, int64_t K, float alpha,
     return PPK_OK;
 }
 
+// Two independent NT problems (C_i = alpha_i A_i B_i^T + beta_i C_i + bias_i) in ONE launch.
+int gemm_nt_pair(const GemmProblem& p0, const GemmProblem& p1, hipStream_t stream)
+{
+    const GemmProblem* ps[2] = {&p0, &p1};
+    GemmBatch gb;
+    gb.grouped = 1;
+    double flops = 0;
+    long long maxMN = 0;
+    for (int i = 0; i < 2; ++i) {
+        const GemmProblem& p = *ps[i];
+        if (p.M == 0 || p.N == 0) PPK_FAIL(PPK_ERR_SHAPE, "gemm_nt_pair: empty problem");
+        int rc = check_problem(0, 1, p.M, p.N, p.K, p.A, p.lda, p.B, p.ldb, p.C, p.ldc);
+        if (rc) return rc;
+        fill_args(gb.p[i], p.M, p.N, p.K, p.alpha, p.A, p.lda, p.B, p.ldb, p.beta, p.C, p.ldc, p.bias);
+        flops += 2.0 * (double)p.M * (double)p.N * (double)p.K;
+        maxMN = maxMN > p.M * p.N ? maxMN : p.M * p.N;
+    }
+    (void)maxMN;
+    dispatch(gb, 2, 0, true, true, flops, stream);
+    PPK_CHECK_LAUNCH("k_gemm(pair)");
+    return PPK_OK;
+}
+
 }  // namespace ppk
 
 extern "C" {
 
 size_t ppk_gemm_f32_workspace_bytes(int64_t M, int64_t N, int64_t K)
 {
-    if (M <= 0 || N <= 0) return 0;
     return ppk::gemm_workspace_bytes(M, N, K);
 }
 

@@ -291,18 +291,21 @@ int ppk_stackgru_seq_fwd(int64_t T, const int64_t* batch_sizes_host, int64_t B, 
         auto hprev = [&](int64_t l) { return t == 0 ? h0 + l * B * H : Hs + (l * NT + op) * H; };
         rc = ppk::gemm(0, 1, Bt, 3 + W, H, 1.f, hprev(L - 1), H, wcs, H, 0.f, csraw, ldcs, bcs, nullptr, 0, stream);
         if (rc) return rc;
+        { ppk::ProfScope prof(ppk::PK_STACK_FWD, 8.0 * (double)Bt * D * W, stream);
         k_stack_fwd<<<dim3((unsigned)Bt), dim3(256), lds_stack, stream>>>(
-            csraw, ldcs, t == 0 ? nullptr : S + op * D * W, S + o * D * W, CS + o * ldcs, X + o * ldx + E, ldx, (int)D, (int)W);
+            csraw, ldcs, t == 0 ? nullptr : S + op * D * W, S + o * D * W, CS + o * ldcs, X + o * ldx + E, ldx, (int)D, (int)W); }
         PPK_CHECK_LAUNCH("k_stack_fwd");
         for (int64_t l = 0; l < L; ++l) {
             const float* in = l == 0 ? X + o * ldx : Hs + ((l - 1) * NT + o) * H;
             const int64_t Il = l == 0 ? I0 : H, ldin = l == 0 ? ldx : H;
-            rc = ppk::gemm(0, 1, Bt, 3 * H, Il, 1.f, in, ldin, w_ih[l], l == 0 ? ld_wih0 : H, 0.f, gi, 3 * H, b_ih[l], nullptr, 0, stream);
+            // both gate GEMMs of the layer-step in one launch
+            const ppk::GemmProblem pi{Bt, 3 * H, Il, 1.f, in, ldin, w_ih[l], l == 0 ? ld_wih0 : H, 0.f, gi, 3 * H, b_ih[l]};
+            const ppk::GemmProblem ph{Bt, 3 * H, H, 1.f, hprev(l), H, w_hh[l], H, 0.f, gh, 3 * H, b_hh[l]};
+            rc = ppk::gemm_nt_pair(pi, ph, stream);
             if (rc) return rc;
-            rc = ppk::gemm(0, 1, Bt, 3 * H, H, 1.f, hprev(l), H, w_hh[l], H, 0.f, gh, 3 * H, b_hh[l], nullptr, 0, stream);
-            if (rc) return rc;
+            { ppk::ProfScope prof(ppk::PK_GATE_FWD, 4.0 * 13 * (double)Bt * H, stream);
             k_gate_fwd<<<dim3(grid_for(Bt * H / 4)), dim3(256), 0, stream>>>(
-                gi, gh, hprev(l), (int)Bt, (int)H, Hs + (l * NT + o) * H, HP + (l * NT + o) * H, gates + (l * NT + o) * 4 * H);
+                gi, gh, hprev(l), (int)Bt, (int)H, Hs + (l * NT + o) * H, HP + (l * NT + o) * H, gates + (l * NT + o) * 4 * H); }
             PPK_CHECK_LAUNCH("k_gate_fwd");
         }
     }
@@ -319,9 +322,11 @@ size_t ppk_stackgru_seq_bwd_workspace_bytes(int64_t B, int64_t H, int64_t W, int
 // (decoder: from the logits; encoder: zero except each sequence's last step).
 // Outputs: dX [NT, ldx], DGI / DGH [L, NT, 3H], DCS [NT, ldcs], dh0 [L, B, H].
 // The weight gradients are single large GEMMs over these (host side).
+// Weights arrive TRANSPOSED (w_ih_t[l] [I_l, 3H], w_hh_t[l] [H, 3H], wcs_t [H, ldcs])
+// so that every per-step data-gradient GEMM reads k-contiguous operands.
 int ppk_stackgru_seq_bwd(int64_t T, const int64_t* batch_sizes_host, int64_t B, int64_t NT,
                          int64_t V, int64_t E, int64_t H, int64_t L, int64_t W, int64_t D,
-                         const float* const* w_ih, int64_t ld_wih0, const float* const* w_hh, const float* wcs,
+                         const float* const* w_ih_t, const float* const* w_hh_t, const float* wcs_t,
                          const float* HP, const float* gates, const float* S, const float* CS, int64_t ldcs,
                          const float* dHtop, float* dX, int64_t ldx, float* DGI, float* DGH, float* DCS,
                          float* dh0, void* workspace, size_t ws_bytes, hipStream_t stream)
@@ -330,10 +335,9 @@ int ppk_stackgru_seq_bwd(int64_t T, const int64_t* batch_sizes_host, int64_t B, 
     std::vector<int64_t> off;
     int rc = check_dims(d, batch_sizes_host, off);
     if (rc) return rc;
-    if (!w_ih || !w_hh || !wcs || !HP || !gates || !S || !CS || !dHtop || !dX || !DGI || !DGH || !DCS || !dh0 || !workspace)
+    if (!w_ih_t || !w_hh_t || !wcs_t || !HP || !gates || !S || !CS || !dHtop || !dX || !DGI || !DGH || !DCS || !dh0 || !workspace)
         PPK_FAIL(PPK_ERR_NULL, "stackgru_seq_bwd: null pointer");
     if (ws_bytes < ppk_stackgru_seq_bwd_workspace_bytes(B, H, W, D)) PPK_FAIL(PPK_ERR_WS, "stackgru_seq_bwd: workspace too small");
-    if (ld_wih0 < E + W) PPK_FAIL(PPK_ERR_SHAPE, "stackgru_seq_bwd: ld_wih0 < E + W");
     char* cur = (char*)workspace;
     const size_t sbytes = sizeof(float) * (size_t)B * D * W;
     float* dSa = (float*)ppk_carve(cur, sbytes);
@@ -351,21 +355,25 @@ int ppk_stackgru_seq_bwd(int64_t T, const int64_t* batch_sizes_host, int64_t B, 
             float* carry = dh0 + l * B * H;
             float* dgi = DGI + (l * NT + o) * 3 * H;
             float* dgh = DGH + (l * NT + o) * 3 * H;
+            { ppk::ProfScope prof(ppk::PK_GATE_BWD, 4.0 * 14 * (double)Bt * H, stream);
             k_gate_bwd<<<dim3(grid_for(Bt * H / 4)), dim3(256), 0, stream>>>(
                 carry, l == L - 1 ? dHtop + o * H : nullptr, l < L - 1 ? dxup : nullptr,
-                gates + (l * NT + o) * 4 * H, HP + (l * NT + o) * H, (int)Bt, (int)H, dgi, dgh);
+                gates + (l * NT + o) * 4 * H, HP + (l * NT + o) * H, (int)Bt, (int)H, dgi, dgh); }
             PPK_CHECK_LAUNCH("k_gate_bwd");
-            rc = ppk::gemm(0, 0, Bt, H, 3 * H, 1.f, dgh, 3 * H, w_hh[l], H, 1.f, carry, H, nullptr, nullptr, 0, stream);
-            if (rc) return rc;
-            if (l > 0) rc = ppk::gemm(0, 0, Bt, H, 3 * H, 1.f, dgi, 3 * H, w_ih[l], H, 0.f, dxup, H, nullptr, nullptr, 0, stream);
-            else       rc = ppk::gemm(0, 0, Bt, I0, 3 * H, 1.f, dgi, 3 * H, w_ih[0], ld_wih0, 0.f, dX + o * ldx, ldx, nullptr, nullptr, 0, stream);
+            // carry += dgh . W_hh  and  dx = dgi . W_ih  (pre-transposed weights -> k-contiguous operands) in one launch
+            const ppk::GemmProblem pc{Bt, H, 3 * H, 1.f, dgh, 3 * H, w_hh_t[l], 3 * H, 1.f, carry, H, nullptr};
+            const ppk::GemmProblem px = l > 0
+                ? ppk::GemmProblem{Bt, H, 3 * H, 1.f, dgi, 3 * H, w_ih_t[l], 3 * H, 0.f, dxup, H, nullptr}
+                : ppk::GemmProblem{Bt, I0, 3 * H, 1.f, dgi, 3 * H, w_ih_t[0], 3 * H, 0.f, dX + o * ldx, ldx, nullptr};
+            rc = ppk::gemm_nt_pair(pc, px, stream);
             if (rc) return rc;
         }
+        { ppk::ProfScope prof(ppk::PK_STACK_BWD, 12.0 * (double)Bt * D * W, stream);
         k_stack_bwd<<<dim3((unsigned)Bt), dim3(256), lds_stack, stream>>>(
-            dSa, dX + o * ldx + E, ldx, t == 0 ? nullptr : S + op * D * W, CS + o * ldcs, ldcs, DCS + o * ldcs, dSb, (int)D, (int)W);
+            dSa, dX + o * ldx + E, ldx, t == 0 ? nullptr : S + op * D * W, CS + o * ldcs, ldcs, DCS + o * ldcs, dSb, (int)D, (int)W); }
         PPK_CHECK_LAUNCH("k_stack_bwd");
         float* tmp = dSa; dSa = dSb; dSb = tmp;
-        rc = ppk::gemm(0, 0, Bt, H, 3 + W, 1.f, DCS + o * ldcs, ldcs, wcs, H, 1.f, dh0 + (L - 1) * B * H, H, nullptr, nullptr, 0, stream);
+        rc = ppk::gemm(0, 1, Bt, H, 3 + W, 1.f, DCS + o * ldcs, ldcs, wcs_t, ldcs, 1.f, dh0 + (L - 1) * B * H, H, nullptr, nullptr, 0, stream);
         if (rc) return rc;
     }
     return PPK_OK;

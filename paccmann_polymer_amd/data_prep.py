@@ -1,0 +1,157 @@
+"""Batch / index construction either side of the hot path (host side, integers).
+
+Mirrors
+  experiments/chem_reactions/utils.py:35-98    packed_sequential_data_preparation
+  experiments/chem_reactions/reactions_vae.py:79-83   hop-distance matrix (Floyd–Warshall, networkx order)
+  experiments/chem_reactions/utils.py:155-196  bundle sampler of load_data
+with bit-exact integer outputs (tests/test_data_prep.py pins them against
+torch.nn.utils.rnn.pack_sequence and networkx run on the same statements).
+"""
+from typing import List, Sequence
+
+import numpy as np
+import torch
+from torch.nn.utils.rnn import PackedSequence, pack_sequence
+
+
+def packed_sequential_data_preparation(
+    input_batch,
+    input_keep=1,
+    start_index=2,
+    end_index=3,
+    dropout_index=1,
+    device=None,
+    enforce_sorted=False,
+):
+    """Reference utils.py:35-98 (same signature; `start_index` / `end_index` are
+    unused there too).  Returns [encoder_seq, decoder_seq, target_seq] as
+    PackedSequences whose `.data` lives on `device`."""
+    if device is None:
+        device = torch.device('cuda' if torch.cuda.is_available() else 'cpu')
+
+    def _process_sample(sample):
+        if len(sample.shape) != 1:
+            raise ValueError
+        inp = sample.long()
+        decoder = inp.clone()
+        if input_keep != 1:
+            mask = torch.distributions.bernoulli.Bernoulli(input_keep).sample(inp.shape)
+            decoder[mask.cpu() == 0] = dropout_index
+        target = torch.cat([inp[1:].detach().clone(), torch.zeros(1, dtype=torch.int64, device=inp.device)])
+        return inp, decoder, target
+
+    batch = [_process_sample(s) for s in input_batch]
+    out = []
+    for entry in zip(*batch):
+        # pack on the host (index arithmetic), ship the token stream once
+        packed = pack_sequence([e.cpu() for e in entry], enforce_sorted=enforce_sorted)
+        out.append(PackedSequence(packed.data.to(device), packed.batch_sizes,
+                                  None if packed.sorted_indices is None else packed.sorted_indices.to(device),
+                                  None if packed.unsorted_indices is None else packed.unsorted_indices.to(device)))
+    return out
+
+
+def networkx_node_order(edge_index, num_nodes: int) -> List[int]:
+    """Row order of `nx.floyd_warshall_numpy(graph)` for the graph built at
+    reactions_vae.py:79-80: nodes in order of first appearance in the edge list
+    (u then v per edge), then the remaining `range(num_nodes)` (Quirk C)."""
+    ei = np.asarray(edge_index.cpu() if torch.is_tensor(edge_index) else edge_index, dtype=np.int64)
+    order, seen = [], set()
+    if ei.size:
+        for u, v in ei.T.tolist():
+            for x in (u, v):
+                if x not in seen:
+                    seen.add(x)
+                    order.append(x)
+    for x in range(num_nodes):
+        if x not in seen:
+            seen.add(x)
+            order.append(x)
+    return order
+
+
+def hop_distance_matrix(edge_index, num_nodes: int, order: str = 'networkx') -> np.ndarray:
+    """reactions_vae.py:79-83: undirected all-pairs hop counts, `inf -> 0`,
+    float64.  `order='networkx'` reproduces the reference's row/column order
+    (insertion order, Quirk C); `order='index'` orders rows by node index."""
+    ei = np.asarray(edge_index.cpu() if torch.is_tensor(edge_index) else edge_index, dtype=np.int64)
+    if order == 'networkx':
+        nodes = networkx_node_order(ei, num_nodes)
+    elif order == 'index':
+        labels = set(range(num_nodes)) | set(ei.reshape(-1).tolist())
+        nodes = sorted(labels)
+    else:
+        raise ValueError(order)
+    n = len(nodes)
+    pos = {x: i for i, x in enumerate(nodes)}
+    adj = [[] for _ in range(n)]
+    if ei.size:
+        for u, v in ei.T.tolist():
+            if u != v:
+                adj[pos[u]].append(pos[v])
+                adj[pos[v]].append(pos[u])
+    dist = np.zeros((n, n), dtype=np.float64)           # unreachable and diagonal stay 0
+    for s in range(n):                                  # BFS per source == Floyd–Warshall on unit weights
+        seen = np.full(n, -1, dtype=np.int64)
+        seen[s] = 0
+        frontier = [s]
+        while frontier:
+            nxt = []
+            for a in frontier:
+                for b in adj[a]:
+                    if seen[b] < 0:
+                        seen[b] = seen[a] + 1
+                        nxt.append(b)
+            frontier = nxt
+        reach = seen > 0
+        dist[s, reach] = seen[reach]
+    return dist
+
+
+def sample_bundle(neighbors, root, max_close_neighbors=5, max_total_bundle=20, rng=np.random):
+    """Shortlist of edges for one root (utils.py:161-179).  `neighbors(x)` lists
+    x's neighbours in adjacency insertion order; `rng` is the numpy global RNG
+    module by default, like the reference."""
+    close = rng.permutation(list(neighbors(root)))[:max_close_neighbors]
+    total_far = sum(len(list(neighbors(x))) for x in close)
+    shortlist = [[root, x] for x in close]
+    counter = 0
+    while len(shortlist) < max_total_bundle and counter < total_far:
+        cur = close[counter % len(close)]
+        far = rng.choice(list(neighbors(cur)))
+        shortlist.append([cur, far])
+        counter += 1
+    return shortlist
+
+
+def relabel_bundle(shortlist):
+    """utils.py:183-194: undirected graph from the shortlist (duplicates merged),
+    nodes relabelled by first appearance; returns (original_labels, edge_index [2, E])
+    with each undirected edge once, ordered by node then adjacency insertion order
+    (what `nx.to_pandas_edgelist(convert_node_labels_to_integers(...))` yields)."""
+    order, pos, adj = [], {}, {}
+
+    def add(x):
+        if x not in pos:
+            pos[x] = len(order)
+            order.append(x)
+            adj[x] = []
+
+    for u, v in shortlist:
+        u, v = int(u), int(v)
+        add(u)
+        add(v)
+        if v not in adj[u]:
+            adj[u].append(v)
+            if u != v:
+                adj[v].append(u)
+    edges, seen = [], set()
+    for u in order:
+        for v in adj[u]:
+            key = (min(pos[u], pos[v]), max(pos[u], pos[v]))
+            if key in seen:
+                continue
+            seen.add(key)
+            edges.append([pos[u], pos[v]])
+    ei = np.asarray(edges, dtype=np.int64).reshape(-1, 2).T
+    return order, ei

@@ -219,7 +219,12 @@ class _StackGRUSeq(torch.autograd.Function):
             _ptr_array(b_ih), _ptr_array(b_hh), _C.p(wcs), _C.p(bcs), _C.p(h0),
             _C.p(X), ldx, _C.p(Hs), _C.p(HP), _C.p(gates), _C.p(S), _C.p(CS), ldcs,
             _C.p(ws), wsb, _C.stream()))
-        ctx.save_for_backward(tokens, X, Hs, HP, gates, S, CS, wcs, *w_ih_use, *w_hh_use)
+        # transposed copies for the backward's data-gradient GEMMs (k-contiguous operands)
+        wcs_t = torch.zeros(H, ldcs, dtype=torch.float32, device=dev)
+        wcs_t[:, :3 + W] = wcs.t()
+        w_ih_t = [w_ih[0].t().contiguous()] + [w.t().contiguous() for w in w_ih[1:]]
+        w_hh_t = [w.t().contiguous() for w in w_hh]
+        ctx.save_for_backward(tokens, X, Hs, HP, gates, S, CS, wcs_t, *w_ih_t, *w_hh_t)
         ctx.bs_host = bs_host
         ctx.dims = (V, E, H, L, W, D, T, B, NT, ldx, ldcs, I0)
         ctx.padding_idx = -1 if pad is None else int(pad)
@@ -229,9 +234,9 @@ class _StackGRUSeq(torch.autograd.Function):
     def backward(ctx, dHtop):
         V, E, H, L, W, D, T, B, NT, ldx, ldcs, I0 = ctx.dims
         saved = ctx.saved_tensors
-        tokens, X, Hs, HP, gates, S, CS, wcs = saved[:8]
-        w_ih_use = list(saved[8:8 + L])
-        w_hh_use = list(saved[8 + L:8 + 2 * L])
+        tokens, X, Hs, HP, gates, S, CS, wcs_t = saved[:8]
+        w_ih_t = list(saved[8:8 + L])
+        w_hh_t = list(saved[8 + L:8 + 2 * L])
         dev = X.device
         f32 = dict(dtype=torch.float32, device=dev)
         dHtop = dHtop.contiguous()
@@ -245,7 +250,7 @@ class _StackGRUSeq(torch.autograd.Function):
         st = _C.stream()
         _C.check(_lib.ppk_stackgru_seq_bwd(
             T, ctypes.c_void_p(ctx.bs_host.data_ptr()), B, NT, V, E, H, L, W, D,
-            _ptr_array(w_ih_use), ldx, _ptr_array(w_hh_use), _C.p(wcs),
+            _ptr_array(w_ih_t), _ptr_array(w_hh_t), _C.p(wcs_t),
             _C.p(HP), _C.p(gates), _C.p(S), _C.p(CS), ldcs,
             _C.p(dHtop), _C.p(dX), ldx, _C.p(DGI), _C.p(DGH), _C.p(DCS), _C.p(dh0),
             _C.p(ws), wsb, st))

@@ -179,6 +179,33 @@ int ppk_reparam_bwd(const float* mu, const float* logvar, const float* eps, int6
 int ppk_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
                   float lr, float beta1, float beta2, float eps, float weight_decay, int64_t step, ppk_stream_t stream);
 
+/* ---- K6: CSR build (stable sort of edge_index by target) --------------------
+ * gcn_norm + the grouping that torch_scatter.scatter_add performs implicitly inside
+ * torch_geometric GCNConv (reference reactions_infomax.py:60,66).
+ * Row i of the CSR lists the edges whose target is i in ORIGINAL edge-list order,
+ * the appended self loop last.  rowptr [N+1], col / eid / val [E + N] (nnz = rowptr[N]).
+ * eid is the original edge id (E + i for node i's self loop).  status [1] (device int)
+ * becomes non-zero if an endpoint was out of range (those edges are skipped). */
+size_t ppk_csr_build_workspace_bytes(int64_t N, int64_t E);
+int ppk_csr_build(const int64_t* src, const int64_t* dst, int64_t E, int64_t N, int drop_self_loops, int add_self_loops,
+                  int normalize, const float* edge_weight, int64_t* rowptr, int64_t* col, int64_t* eid, float* val,
+                  int* status, void* workspace, size_t ws_bytes, ppk_stream_t stream);
+/* ---- K7: out[i, :] = sum_{j in row i} val[j] * x[col[j], :] --------------------
+ * One wavefront per row, fixed order, no atomics (GCNConv.propagate's gather +
+ * scatter_add).  The backward is the same call on the CSR of the reversed edges. */
+int ppk_spmm_csr(const int64_t* rowptr, const int64_t* col, const float* val, int64_t N, int64_t nnz,
+                 const float* x, int64_t ldx, int64_t F, float* out, int64_t ldo, ppk_stream_t stream);
+
+/* ---- PReLU and the DeepGraphInfomax loss (reactions_infomax.py:61,67,131-132,251-264) */
+int ppk_prelu_fwd(const float* x, const float* alpha, int64_t rows, int64_t C, float* y, ppk_stream_t stream);
+int ppk_prelu_bwd(const float* x, const float* alpha, const float* dy, int64_t rows, int64_t C, float* dx, float* t,
+                  ppk_stream_t stream);
+size_t ppk_dgi_loss_workspace_bytes(int64_t N);
+int ppk_dgi_loss_fwd(const float* pos_logit, const float* neg_logit, int64_t N, float* loss, void* workspace, size_t ws_bytes,
+                     ppk_stream_t stream);
+int ppk_dgi_loss_bwd(const float* pos_logit, const float* neg_logit, int64_t N, const float* dloss, float* dpos, float* dneg,
+                     ppk_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

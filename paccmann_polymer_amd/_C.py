@@ -63,6 +63,14 @@ SIGNATURES = {
     'ppk_reparam_fwd': (c_int, [ptr, ptr, ptr, c_i64, ptr, ptr, ptr, c_sz, ptr]),
     'ppk_reparam_bwd': (c_int, [ptr, ptr, ptr, c_i64, ptr, ptr, ptr, ptr, ptr]),
     'ppk_adam_step': (c_int, [ptr, ptr, ptr, ptr, c_i64, c_f32, c_f32, c_f32, c_f32, c_f32, c_i64, ptr]),
+    'ppk_csr_build_workspace_bytes': (c_sz, [c_i64, c_i64]),
+    'ppk_csr_build': (c_int, [ptr, ptr, c_i64, c_i64, c_int, c_int, c_int, ptr, ptr, ptr, ptr, ptr, ptr, ptr, c_sz, ptr]),
+    'ppk_spmm_csr': (c_int, [ptr, ptr, ptr, c_i64, c_i64, ptr, c_i64, c_i64, ptr, c_i64, ptr]),
+    'ppk_prelu_fwd': (c_int, [ptr, ptr, c_i64, c_i64, ptr, ptr]),
+    'ppk_prelu_bwd': (c_int, [ptr, ptr, ptr, c_i64, c_i64, ptr, ptr, ptr]),
+    'ppk_dgi_loss_workspace_bytes': (c_sz, [c_i64]),
+    'ppk_dgi_loss_fwd': (c_int, [ptr, ptr, c_i64, ptr, ptr, c_sz, ptr]),
+    'ppk_dgi_loss_bwd': (c_int, [ptr, ptr, c_i64, ptr, ptr, ptr, ptr]),
 }
 
 

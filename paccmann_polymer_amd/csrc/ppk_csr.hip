@@ -1,0 +1,356 @@
+// K6 — CSR build (stable sort of the edge list by target) and
+// K7 — CSR gather + segmented-reduce SpMM (forward and, on the transposed CSR, backward).
+//
+// Replaces the message passing of torch_geometric GCNConv / torch_scatter
+// scatter_add that the reference calls at
+//   .../experiments/chem_reactions/reactions_infomax.py:60,66   (GCNConv(256, 512)(x, edge_index))
+// (gcn_norm + gather x_j + scatter-add at the target; semantics SURVEY.md Appendix C).
+// scatter_add on a GPU uses float atomics (run-to-run different bits); here every
+// output row is reduced by ONE wavefront in CSR order, so the result is deterministic
+// and equals a CPU scatter_add that walks the edge list in order:
+//   row i = edges with target i in ORIGINAL edge-list order, self loop last.
+//
+// CSR build without a global sort: integer histogram -> exclusive scan -> atomic
+// fill (arbitrary order inside a row) -> per-row sort by edge id (unique keys, so the
+// final order is deterministic).  Short rows are sorted by one lane each, long rows
+// (hubs of power-law relation graphs) by a workgroup bitonic sort in LDS.
+#include "ppk_common.h"
+#include "ppk_kernels.h"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int SCAN_BLOCK = 1024;     // elements per scan block (256 threads x 4)
+constexpr int SHORT_ROW = 16;
+constexpr int LDS_SORT_MAX = 8192;
+
+inline unsigned grid_for(long long work, unsigned cap = 8192)
+{
+    long long b = (work + 255) / 256;
+    if (b < 1) b = 1;
+    return (unsigned)(b < cap ? b : cap);
+}
+
+// cnt[target] += 1 for every non-self-loop edge (integer atomics: order-independent result)
+__global__ __launch_bounds__(256) void k_count(const int64_t* __restrict__ src, const int64_t* __restrict__ dst, long long E,
+                                               long long N, int drop_self_loops, int* __restrict__ cnt, int* __restrict__ bad)
+{
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < E; e += (long long)gridDim.x * 256) {
+        const long long s = src[e], d = dst[e];
+        if (s < 0 || s >= N || d < 0 || d >= N) { atomicOr(bad, 1); continue; }
+        if (drop_self_loops && s == d) continue;
+        atomicAdd(&cnt[d], 1);
+    }
+}
+
+// ---- exclusive scan of (cnt[i] + extra) over N entries -> rowptr (int64) ------
+__global__ __launch_bounds__(256) void k_scan_block(const int* __restrict__ cnt, int extra, long long N,
+                                                    long long* __restrict__ rowptr, long long* __restrict__ block_sums)
+{
+    __shared__ long long wsum[4];
+    const long long base = (long long)blockIdx.x * SCAN_BLOCK + threadIdx.x * 4;
+    long long v[4], tot = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        v[k] = (base + k < N) ? (long long)cnt[base + k] + extra : 0;
+        tot += v[k];
+    }
+    // inclusive scan of `tot` across the block
+    long long inc = tot;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        long long t = __shfl_up(inc, o, 64);
+        if (lane >= o) inc += t;
+    }
+    if (lane == 63) wsum[wave] = inc;
+    __syncthreads();
+    long long woff = 0;
+    for (int w = 0; w < wave; ++w) woff += wsum[w];
+    long long excl = woff + inc - tot;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        if (base + k < N) rowptr[base + k] = excl;     // block-local exclusive prefix
+        excl += v[k];
+    }
+    if (threadIdx.x == 255) block_sums[blockIdx.x] = woff + inc;
+}
+__global__ __launch_bounds__(256) void k_scan_sums(long long* __restrict__ block_sums, int nblocks, long long* __restrict__ total_out)
+{
+    // single block: sequential chunks of 256 with a running carry (nblocks <= a few thousand)
+    __shared__ long long wsum[4];
+    __shared__ long long carry_s;
+    if (threadIdx.x == 0) carry_s = 0;
+    __syncthreads();
+    for (int b0 = 0; b0 < nblocks; b0 += 256) {
+        const int i = b0 + threadIdx.x;
+        const long long v = i < nblocks ? block_sums[i] : 0;
+        long long inc = v;
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            long long t = __shfl_up(inc, o, 64);
+            if (lane >= o) inc += t;
+        }
+        if (lane == 63) wsum[wave] = inc;
+        __syncthreads();
+        long long woff = 0;
+        for (int w = 0; w < wave; ++w) woff += wsum[w];
+        const long long carry = carry_s;
+        if (i < nblocks) block_sums[i] = carry + woff + inc - v;    // exclusive
+        __syncthreads();
+        if (threadIdx.x == 255) carry_s = carry + woff + inc;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *total_out = carry_s;
+}
+__global__ __launch_bounds__(256) void k_scan_add(long long* __restrict__ rowptr, const long long* __restrict__ block_sums,
+                                                  const long long* __restrict__ total, long long N)
+{
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i < N) rowptr[i] += block_sums[i / SCAN_BLOCK];
+    if (i == N) rowptr[N] = *total;
+}
+
+// fill: arbitrary position inside the row; the self loop gets edge id E + i (sorts last)
+__global__ __launch_bounds__(256) void k_fill(const int64_t* __restrict__ src, const int64_t* __restrict__ dst, long long E,
+                                              long long N, int drop_self_loops, int add_self_loops,
+                                              const long long* __restrict__ rowptr, int* __restrict__ cursor,
+                                              long long* __restrict__ eid)
+{
+    const long long total = E + (add_self_loops ? N : 0);
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+        long long d;
+        if (e < E) {
+            const long long s = src[e];
+            d = dst[e];
+            if (s < 0 || s >= N || d < 0 || d >= N) continue;
+            if (drop_self_loops && s == d) continue;
+        } else {
+            d = e - E;
+        }
+        const int pos = atomicAdd(&cursor[d], 1);
+        eid[rowptr[d] + pos] = e;
+    }
+}
+
+// per-row sort by edge id.  Short rows: one lane each.  Long rows are queued.
+__global__ __launch_bounds__(256) void k_sort_short(const long long* __restrict__ rowptr, long long N, long long* __restrict__ eid,
+                                                    int* __restrict__ long_rows, int* __restrict__ n_long)
+{
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < N; i += (long long)gridDim.x * 256) {
+        const long long b = rowptr[i], len = rowptr[i + 1] - b;
+        if (len <= 1) continue;
+        if (len > SHORT_ROW) { long_rows[atomicAdd(n_long, 1)] = (int)i; continue; }
+        long long v[SHORT_ROW];
+#pragma unroll
+        for (int k = 0; k < SHORT_ROW; ++k) v[k] = k < len ? eid[b + k] : 0x7fffffffffffffffLL;
+        // odd-even transposition network on registers (fully unrolled, no dynamic indexing)
+#pragma unroll
+        for (int pass = 0; pass < SHORT_ROW; ++pass)
+#pragma unroll
+            for (int k = pass & 1; k + 1 < SHORT_ROW; k += 2) {
+                const long long lo = v[k] < v[k + 1] ? v[k] : v[k + 1];
+                const long long hi = v[k] < v[k + 1] ? v[k + 1] : v[k];
+                v[k] = lo; v[k + 1] = hi;
+            }
+#pragma unroll
+        for (int k = 0; k < SHORT_ROW; ++k)
+            if (k < len) eid[b + k] = v[k];
+    }
+}
+// long rows: one workgroup per row, bitonic sort (LDS when it fits, global otherwise)
+__global__ __launch_bounds__(256) void k_sort_long(const long long* __restrict__ rowptr, long long* __restrict__ eid,
+                                                   const int* __restrict__ long_rows, const int* __restrict__ n_long)
+{
+    __shared__ long long buf[LDS_SORT_MAX];
+    const int nl = *n_long;
+    for (int q = blockIdx.x; q < nl; q += gridDim.x) {
+        const long long i = long_rows[q];
+        const long long b = rowptr[i];
+        const int len = (int)(rowptr[i + 1] - b);
+        if (len <= LDS_SORT_MAX) {
+            int n2 = 1;
+            while (n2 < len) n2 <<= 1;
+            for (int k = threadIdx.x; k < n2; k += 256) buf[k] = k < len ? eid[b + k] : 0x7fffffffffffffffLL;
+            __syncthreads();
+            for (int size = 2; size <= n2; size <<= 1)
+                for (int stride = size >> 1; stride > 0; stride >>= 1) {
+                    for (int k = threadIdx.x; k < n2 / 2; k += 256) {
+                        const int lo = 2 * k - (k & (stride - 1));
+                        const int hi = lo + stride;
+                        const bool up = (lo & size) == 0;
+                        const long long a = buf[lo], c = buf[hi];
+                        if ((a > c) == up) { buf[lo] = c; buf[hi] = a; }
+                    }
+                    __syncthreads();
+                }
+            for (int k = threadIdx.x; k < len; k += 256) eid[b + k] = buf[k];
+            __syncthreads();
+        } else {
+            // very long row: odd-even transposition sort in global memory by this workgroup (rare; O(len^2 / 256))
+            long long* a = eid + b;
+            for (int pass = 0; pass < len; ++pass) {
+                for (int k = (pass & 1) + 2 * threadIdx.x; k + 1 < len; k += 512) {
+                    const long long x = a[k], y = a[k + 1];
+                    if (x > y) { a[k] = y; a[k + 1] = x; }
+                }
+                __syncthreads();
+            }
+        }
+    }
+}
+
+// sources and symmetric-normalisation weights in CSR order
+__global__ __launch_bounds__(256) void k_finish(const int64_t* __restrict__ src, long long E, long long N,
+                                                const long long* __restrict__ rowptr, const long long* __restrict__ eid,
+                                                const int* __restrict__ deg_cnt, int deg_extra, int normalize,
+                                                const float* __restrict__ edge_weight,
+                                                long long* __restrict__ col, float* __restrict__ val)
+{
+    // one thread per row walks its entries (rows are short on average); grid-stride
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < N; i += (long long)gridDim.x * 256) {
+        const float di = normalize ? rsqrtf((float)(deg_cnt[i] + deg_extra)) : 1.0f;
+        for (long long j = rowptr[i]; j < rowptr[i + 1]; ++j) {
+            const long long e = eid[j];
+            const long long s = e < E ? src[e] : e - E;
+            col[j] = s;
+            float w = (e < E && edge_weight) ? edge_weight[e] : 1.0f;
+            if (normalize) w *= di * rsqrtf((float)(deg_cnt[s] + deg_extra));
+            val[j] = w;
+        }
+    }
+}
+
+// ---- K7: out[i, :] = sum_j val[j] * x[col[j], :]   one wavefront per row -------
+template <int VEC>   // floats per lane per pass (4 -> float4)
+__global__ __launch_bounds__(256) void k_spmm(const long long* __restrict__ rowptr, const long long* __restrict__ col,
+                                              const float* __restrict__ val, const float* __restrict__ x, long long ldx,
+                                              long long N, int F, float* __restrict__ out, long long ldo)
+{
+    const int lane = threadIdx.x & 63;
+    const long long wave_global = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const long long nwaves = (long long)gridDim.x * 4;
+    for (long long i = wave_global; i < N; i += nwaves) {
+        const long long b = rowptr[i], e = rowptr[i + 1];
+        for (int f0 = lane * VEC; f0 < F; f0 += 64 * VEC) {
+            if constexpr (VEC == 4) {
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+                long long j = b;
+                for (; j + 1 < e; j += 2) {            // two gathers in flight
+                    const long long c0 = col[j], c1 = col[j + 1];
+                    const float w0 = val[j], w1 = val[j + 1];
+                    const f32x4 v0 = *(const f32x4*)(x + c0 * ldx + f0);
+                    const f32x4 v1 = *(const f32x4*)(x + c1 * ldx + f0);
+                    acc += w0 * v0;
+                    acc += w1 * v1;
+                }
+                if (j < e) acc += val[j] * *(const f32x4*)(x + col[j] * ldx + f0);
+                *(f32x4*)(out + i * ldo + f0) = acc;
+            } else {
+                float acc = 0.f;
+                for (long long j = b; j < e; ++j) acc = fmaf(val[j], x[col[j] * ldx + f0], acc);
+                out[i * ldo + f0] = acc;
+            }
+        }
+    }
+}
+
+struct CsrWs { int* cnt; int* cursor; long long* block_sums; long long* total; int* long_rows; int* n_long; int* bad; };
+
+size_t csr_ws_bytes(int64_t N)
+{
+    const size_t nb = (size_t)((N + SCAN_BLOCK - 1) / SCAN_BLOCK);
+    return 3 * ppk_align_up(sizeof(int) * (size_t)N, 256) + ppk_align_up(sizeof(long long) * nb, 256) + 3 * 256;
+}
+CsrWs csr_ws_carve(void* ws, int64_t N)
+{
+    char* cur = (char*)ws;
+    CsrWs w;
+    w.cnt = (int*)ppk_carve(cur, sizeof(int) * (size_t)N);
+    w.cursor = (int*)ppk_carve(cur, sizeof(int) * (size_t)N);
+    w.long_rows = (int*)ppk_carve(cur, sizeof(int) * (size_t)N);
+    w.block_sums = (long long*)ppk_carve(cur, sizeof(long long) * (size_t)((N + SCAN_BLOCK - 1) / SCAN_BLOCK));
+    w.total = (long long*)ppk_carve(cur, 256);
+    w.n_long = (int*)ppk_carve(cur, 256);
+    w.bad = (int*)ppk_carve(cur, 256);
+    return w;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t ppk_csr_build_workspace_bytes(int64_t N, int64_t E)
+{
+    (void)E;
+    if (N < 1) return 0;
+    return csr_ws_bytes(N);
+}
+
+// Builds the CSR of the (optionally self-loop-augmented) graph grouped by `dst`:
+//   rowptr [N+1] int64, col [nnz] int64 (= src of each entry), eid [nnz] int64 (original edge id, E + i for
+//   the appended self loop of node i), val [nnz] fp32, with nnz <= E + N (caller allocates E + N entries).
+// Row i lists the edges with dst == i in ORIGINAL edge order, self loop last (stable sort by target).
+//   drop_self_loops / add_self_loops : gcn_norm's remove_self_loops + add_self_loops
+//   normalize : val = deg^-1/2[src] * w * deg^-1/2[dst], deg = weighted in-degree incl. self loop (unit weights only)
+//   edge_weight : optional [E]; must be NULL when normalize != 0
+// status[0] (device int) is set non-zero when an edge endpoint is out of range (such edges are skipped).
+int ppk_csr_build(const int64_t* src, const int64_t* dst, int64_t E, int64_t N, int drop_self_loops, int add_self_loops,
+                  int normalize, const float* edge_weight, int64_t* rowptr, int64_t* col, int64_t* eid, float* val,
+                  int* status, void* workspace, size_t ws_bytes, hipStream_t stream)
+{
+    if (N < 1 || E < 0) PPK_FAIL(PPK_ERR_SHAPE, "csr_build: N < 1 or E < 0");
+    if ((E > 0 && (!src || !dst)) || !rowptr || !col || !eid || !val || !status || !workspace) PPK_FAIL(PPK_ERR_NULL, "csr_build: null pointer");
+    if (N > 0x7fffffff || E + N > 0x7fffffffLL * 4) PPK_FAIL(PPK_ERR_UNSUP, "csr_build: graph too large");
+    if (normalize && edge_weight) PPK_FAIL(PPK_ERR_UNSUP, "csr_build: normalize with edge weights is not implemented");
+    if (ws_bytes < csr_ws_bytes(N)) PPK_FAIL(PPK_ERR_WS, "csr_build: workspace too small");
+    CsrWs w = csr_ws_carve(workspace, N);
+    const int nb = (int)((N + SCAN_BLOCK - 1) / SCAN_BLOCK);
+    PPK_HIP(hipMemsetAsync(w.cnt, 0, sizeof(int) * (size_t)N, stream));
+    PPK_HIP(hipMemsetAsync(w.cursor, 0, sizeof(int) * (size_t)N, stream));
+    PPK_HIP(hipMemsetAsync(w.n_long, 0, 256, stream));
+    PPK_HIP(hipMemsetAsync(w.bad, 0, 256, stream));
+    if (E > 0) {
+        k_count<<<dim3(grid_for(E)), dim3(256), 0, stream>>>(src, dst, E, N, drop_self_loops, w.cnt, w.bad);
+        PPK_CHECK_LAUNCH("k_count");
+    }
+    k_scan_block<<<dim3(nb), dim3(256), 0, stream>>>(w.cnt, add_self_loops ? 1 : 0, N, (long long*)rowptr, w.block_sums);
+    PPK_CHECK_LAUNCH("k_scan_block");
+    k_scan_sums<<<dim3(1), dim3(256), 0, stream>>>(w.block_sums, nb, w.total);
+    PPK_CHECK_LAUNCH("k_scan_sums");
+    k_scan_add<<<dim3((unsigned)((N + 1 + 255) / 256)), dim3(256), 0, stream>>>((long long*)rowptr, w.block_sums, w.total, N);
+    PPK_CHECK_LAUNCH("k_scan_add");
+    k_fill<<<dim3(grid_for(E + N)), dim3(256), 0, stream>>>(src, dst, E, N, drop_self_loops, add_self_loops,
+                                                            (const long long*)rowptr, w.cursor, (long long*)eid);
+    PPK_CHECK_LAUNCH("k_fill");
+    k_sort_short<<<dim3(grid_for(N)), dim3(256), 0, stream>>>((const long long*)rowptr, N, (long long*)eid, w.long_rows, w.n_long);
+    PPK_CHECK_LAUNCH("k_sort_short");
+    k_sort_long<<<dim3(512), dim3(256), 0, stream>>>((const long long*)rowptr, (long long*)eid, w.long_rows, w.n_long);
+    PPK_CHECK_LAUNCH("k_sort_long");
+    k_finish<<<dim3(grid_for(N)), dim3(256), 0, stream>>>(src, E, N, (const long long*)rowptr, (const long long*)eid, w.cnt,
+                                                          add_self_loops ? 1 : 0, normalize, edge_weight, (long long*)col, val);
+    PPK_CHECK_LAUNCH("k_finish");
+    PPK_HIP(hipMemcpyAsync(status, w.bad, sizeof(int), hipMemcpyDeviceToDevice, stream));
+    return PPK_OK;
+}
+
+// out[i, 0:F] = sum_{j in row i} val[j] * x[col[j], 0:F]   (rows in CSR order: deterministic)
+int ppk_spmm_csr(const int64_t* rowptr, const int64_t* col, const float* val, int64_t N, int64_t nnz,
+                 const float* x, int64_t ldx, int64_t F, float* out, int64_t ldo, hipStream_t stream)
+{
+    if (N < 1 || F < 1 || nnz < 0) PPK_FAIL(PPK_ERR_SHAPE, "spmm_csr: bad sizes");
+    if (!rowptr || !col || !val || !x || !out) PPK_FAIL(PPK_ERR_NULL, "spmm_csr: null pointer");
+    if (ldx < F || ldo < F) PPK_FAIL(PPK_ERR_SHAPE, "spmm_csr: leading dimension < F");
+    const unsigned nb = (unsigned)((N + 3) / 4 < 65536 * 4 ? (N + 3) / 4 : 65536 * 4);
+    // algorithmic bytes: one F-row + col + val per entry, one F-row + rowptr per node
+    ppk::ProfScope prof(ppk::PK_SPMM, (double)nnz * (4.0 * F + 12.0) + (double)N * (4.0 * F + 8.0), stream);
+    const bool vec = (F % 4 == 0) && (ldx % 4 == 0) && (ldo % 4 == 0) && !((uintptr_t)x & 15) && !((uintptr_t)out & 15);
+    if (vec) k_spmm<4><<<dim3(nb), dim3(256), 0, stream>>>((const long long*)rowptr, (const long long*)col, val, x, ldx, N, (int)F, out, ldo);
+    else     k_spmm<1><<<dim3(nb), dim3(256), 0, stream>>>((const long long*)rowptr, (const long long*)col, val, x, ldx, N, (int)F, out, ldo);
+    PPK_CHECK_LAUNCH("k_spmm");
+    return PPK_OK;
+}
+
+}  // extern "C"

@@ -212,6 +212,64 @@ __global__ __launch_bounds__(256) void k_adam(float* __restrict__ p, const float
     }
 }
 
+// ---- PReLU (per-channel slope), reactions_infomax.py:61,67 ----------------------
+__global__ __launch_bounds__(256) void k_prelu_fwd(const float* __restrict__ x, const float* __restrict__ alpha, long long rows,
+                                                   int C, float* __restrict__ y)
+{
+    const long long total = rows * C;
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+        const float v = x[e];
+        y[e] = v >= 0.f ? v : alpha[e % C] * v;
+    }
+}
+// dx = dy * (x >= 0 ? 1 : alpha) ; t = (x < 0 ? x * dy : 0)  (column sums of t give dalpha)
+__global__ __launch_bounds__(256) void k_prelu_bwd(const float* __restrict__ x, const float* __restrict__ alpha,
+                                                   const float* __restrict__ dy, long long rows, int C,
+                                                   float* __restrict__ dx, float* __restrict__ t)
+{
+    const long long total = rows * C;
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+        const float v = x[e], g = dy[e];
+        dx[e] = v >= 0.f ? g : alpha[e % C] * g;
+        t[e] = v < 0.f ? v * g : 0.f;
+    }
+}
+
+// ---- DeepGraphInfomax loss on discriminator logits (Appendix C) -----------------
+// loss = -mean log(sigmoid(p) + 1e-15) - mean log(1 - sigmoid(n) + 1e-15)
+__global__ __launch_bounds__(256) void k_dgi_part(const float* __restrict__ p, const float* __restrict__ n, long long N,
+                                                  double* __restrict__ part)
+{
+    __shared__ double sl[4];
+    double acc = 0.0;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < N; i += (long long)gridDim.x * 256) {
+        const float sp = 1.0f / (1.0f + expf(-p[i])), sn = 1.0f / (1.0f + expf(-n[i]));
+        acc -= (double)logf(sp + 1e-15f);
+        acc -= (double)logf(1.0f - sn + 1e-15f);
+    }
+    acc = ppk_wave_sum_d(acc);
+    if ((threadIdx.x & 63) == 0) sl[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) part[blockIdx.x] = (sl[0] + sl[1]) + (sl[2] + sl[3]);
+}
+__global__ __launch_bounds__(64) void k_dgi_final(const double* __restrict__ part, int nparts, long long N, float* __restrict__ loss)
+{
+    double a = 0.0;
+    for (int q = threadIdx.x; q < nparts; q += 64) a += part[q];
+    a = ppk_wave_sum_d(a);
+    if (threadIdx.x == 0) loss[0] = (float)(a / (double)N);
+}
+__global__ __launch_bounds__(256) void k_dgi_bwd(const float* __restrict__ p, const float* __restrict__ n, long long N,
+                                                 const float* __restrict__ dloss, float* __restrict__ dp, float* __restrict__ dn)
+{
+    const float g = dloss[0] / (float)N;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < N; i += (long long)gridDim.x * 256) {
+        const float sp = 1.0f / (1.0f + expf(-p[i])), sn = 1.0f / (1.0f + expf(-n[i]));
+        dp[i] = -g * sp * (1.0f - sp) / (sp + 1e-15f);
+        dn[i] = g * sn * (1.0f - sn) / (1.0f - sn + 1e-15f);
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -375,6 +433,56 @@ int ppk_adam_step(float* param, const float* grad, float* exp_avg, float* exp_av
     k_adam<<<dim3(grid_for(n)), dim3(256), 0, stream>>>(param, grad, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay,
                                                         (float)bc1, (float)sqrt(bc2));
     PPK_CHECK_LAUNCH("k_adam");
+    return PPK_OK;
+}
+
+int ppk_prelu_fwd(const float* x, const float* alpha, int64_t rows, int64_t C, float* y, hipStream_t stream)
+{
+    if (!x || !alpha || !y) PPK_FAIL(PPK_ERR_NULL, "prelu_fwd: null pointer");
+    if (rows < 1 || C < 1) PPK_FAIL(PPK_ERR_SHAPE, "prelu_fwd: bad sizes");
+    k_prelu_fwd<<<dim3(grid_for(rows * C)), dim3(256), 0, stream>>>(x, alpha, rows, (int)C, y);
+    PPK_CHECK_LAUNCH("k_prelu_fwd");
+    return PPK_OK;
+}
+
+// dx [rows, C]; t [rows, C] scratch whose column sums (ppk_colsum) are dalpha
+int ppk_prelu_bwd(const float* x, const float* alpha, const float* dy, int64_t rows, int64_t C, float* dx, float* t,
+                  hipStream_t stream)
+{
+    if (!x || !alpha || !dy || !dx || !t) PPK_FAIL(PPK_ERR_NULL, "prelu_bwd: null pointer");
+    if (rows < 1 || C < 1) PPK_FAIL(PPK_ERR_SHAPE, "prelu_bwd: bad sizes");
+    k_prelu_bwd<<<dim3(grid_for(rows * C)), dim3(256), 0, stream>>>(x, alpha, dy, rows, (int)C, dx, t);
+    PPK_CHECK_LAUNCH("k_prelu_bwd");
+    return PPK_OK;
+}
+
+size_t ppk_dgi_loss_workspace_bytes(int64_t N)
+{
+    (void)N;
+    return ppk_align_up(sizeof(double) * 1024, 256);
+}
+
+int ppk_dgi_loss_fwd(const float* pos_logit, const float* neg_logit, int64_t N, float* loss, void* workspace, size_t ws_bytes,
+                     hipStream_t stream)
+{
+    if (!pos_logit || !neg_logit || !loss || !workspace) PPK_FAIL(PPK_ERR_NULL, "dgi_loss_fwd: null pointer");
+    if (N < 1) PPK_FAIL(PPK_ERR_SHAPE, "dgi_loss_fwd: N < 1");
+    if (ws_bytes < ppk_dgi_loss_workspace_bytes(N)) PPK_FAIL(PPK_ERR_WS, "dgi_loss_fwd: workspace too small");
+    const unsigned nb = grid_for(N, 1024);
+    k_dgi_part<<<dim3(nb), dim3(256), 0, stream>>>(pos_logit, neg_logit, N, (double*)workspace);
+    PPK_CHECK_LAUNCH("k_dgi_part");
+    k_dgi_final<<<dim3(1), dim3(64), 0, stream>>>((const double*)workspace, (int)nb, N, loss);
+    PPK_CHECK_LAUNCH("k_dgi_final");
+    return PPK_OK;
+}
+
+int ppk_dgi_loss_bwd(const float* pos_logit, const float* neg_logit, int64_t N, const float* dloss, float* dpos, float* dneg,
+                     hipStream_t stream)
+{
+    if (!pos_logit || !neg_logit || !dloss || !dpos || !dneg) PPK_FAIL(PPK_ERR_NULL, "dgi_loss_bwd: null pointer");
+    if (N < 1) PPK_FAIL(PPK_ERR_SHAPE, "dgi_loss_bwd: N < 1");
+    k_dgi_bwd<<<dim3(grid_for(N)), dim3(256), 0, stream>>>(pos_logit, neg_logit, N, dloss, dpos, dneg);
+    PPK_CHECK_LAUNCH("k_dgi_bwd");
     return PPK_OK;
 }
 

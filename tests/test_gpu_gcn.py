@@ -1,0 +1,130 @@
+"""GPU parity of K6 (CSR build: bit-exact integers) and K7 (SpMM) / GCNConv /
+PReLU / DeepGraphInfomax against oracle/gcn_ref.py.  Parity versus
+torch_geometric itself is UNPINNED (package absent offline)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def rel(a, b):
+    a = a.detach().double().cpu().reshape(-1)
+    b = b.detach().double().cpu().reshape(-1)
+    return float((a - b).norm() / max(float(b.norm()), 1e-30))
+
+
+def random_graph(rng, n, e, hubs=0, self_loops=True):
+    src = rng.integers(0, n, size=e)
+    dst = rng.integers(0, n, size=e)
+    if hubs:
+        dst[: e // 3] = rng.integers(0, hubs, size=e // 3)      # a few very long rows
+    if not self_loops:
+        dst = np.where(src == dst, (dst + 1) % n, dst)
+    return torch.tensor(np.stack([src, dst]), dtype=torch.int64)
+
+
+@pytest.mark.parametrize('n,e,hubs', [(9, 8, 0), (50, 400, 0), (1000, 30000, 2), (5000, 200000, 1), (7, 0, 0), (3000, 2999, 0)])
+def test_csr_build_bit_exact(n, e, hubs):
+    from oracle import gcn_ref as R
+    from paccmann_polymer_amd.gcn import CSRGraph
+    rng = np.random.default_rng(n + e)
+    ei = random_graph(rng, n, e, hubs)
+    g = CSRGraph(ei.cuda(), n, check=True)
+    rowptr, col, eid, val, _ = g.fwd
+    rp, c, ed, nv = R.csr_ref(ei, n)
+    nnz = int(rp[-1])
+    assert np.array_equal(rowptr.cpu().numpy(), rp)
+    assert np.array_equal(col.cpu().numpy()[:nnz], c)
+    assert np.array_equal(eid.cpu().numpy()[:nnz], ed)
+    assert np.allclose(val.cpu().numpy()[:nnz], nv, rtol=1e-6, atol=0)
+    # reversed CSR: same multiset of (src, dst, weight), grouped by source, edge order kept
+    rrow, rcol, reid, rval, _ = g.rev
+    assert int(rrow[-1]) == e + n
+    rr = rrow.cpu().numpy()
+    src_aug = np.concatenate([ei[0].numpy(), np.arange(n)])
+    for i in rng.integers(0, n, size=min(n, 20)):
+        ids = reid.cpu().numpy()[rr[i]:rr[i + 1]]
+        assert np.all(src_aug[ids] == i) and np.all(np.diff(ids) > 0)
+
+
+def test_reference_example_edge_index():
+    # SURVEY §0.4 example; one direction per undirected edge
+    from oracle import gcn_ref as R
+    from paccmann_polymer_amd.gcn import GCNConv
+    ei = torch.tensor([[0, 0, 1, 1, 1, 1, 2, 2], [1, 2, 3, 5, 7, 8, 4, 6]])
+    torch.manual_seed(0)
+    conv = GCNConv(16, 32).cuda()
+    x = torch.randn(9, 16)
+    out = conv(x.cuda(), ei.cuda())
+    ref = R.gcn_conv_ref(x.double(), ei, conv.weight.detach().cpu().double(), conv.bias.detach().cpu().double())
+    assert rel(out, ref) <= 1e-6
+
+
+@pytest.mark.parametrize('n,e,fin,fout', [(200, 1500, 256, 512), (64, 300, 30, 7), (4000, 50000, 64, 64)])
+def test_gcnconv_fwd_bwd(n, e, fin, fout):
+    from oracle import gcn_ref as R
+    from paccmann_polymer_amd.gcn import GCNConv
+    rng = np.random.default_rng(e)
+    ei = random_graph(rng, n, e, hubs=1)
+    torch.manual_seed(1)
+    conv = GCNConv(fin, fout).cuda()
+    with torch.no_grad():
+        conv.bias.uniform_(-0.1, 0.1)
+    x = torch.randn(n, fin)
+    xg = x.cuda().requires_grad_(True)
+    out = conv(xg, ei.cuda())
+    wgt = torch.randn(n, fout)
+    (out * wgt.cuda()).sum().backward()
+    xr = x.double().requires_grad_(True)
+    wr = conv.weight.detach().cpu().double().requires_grad_(True)
+    br = conv.bias.detach().cpu().double().requires_grad_(True)
+    ref = R.gcn_conv_ref(xr, ei, wr, br)
+    (ref * wgt.double()).sum().backward()
+    assert rel(out, ref) <= 1e-5
+    assert rel(xg.grad, xr.grad) <= 1e-4
+    assert rel(conv.weight.grad, wr.grad) <= 1e-4
+    assert rel(conv.bias.grad, br.grad) <= 1e-4
+    # deterministic: bitwise equal on a second run
+    out2 = conv(xg, ei.cuda())
+    assert torch.equal(out, out2)
+
+
+def test_dgi_pipeline():
+    from oracle import gcn_ref as R
+    from paccmann_polymer_amd.gcn import DeepGraphInfomax, GraphEncoder
+    rng = np.random.default_rng(5)
+    n, fin, hid = 21, 24, 40
+    ei = random_graph(rng, n, 20, self_loops=False)
+    torch.manual_seed(2)
+    perm = torch.randperm(n)
+    enc = GraphEncoder(fin, hid).cuda()
+    model = DeepGraphInfomax(hid, enc, corruption=lambda x, e: (x[perm.to(x.device)], e)).cuda()
+    x = torch.randn(n, fin)
+    pos, neg, s = model(x.cuda(), ei.cuda())
+    loss = model.loss(pos, neg, s)
+    loss.backward()
+    # reference in fp64
+    W = enc.conv.weight.detach().cpu().double().requires_grad_(True)
+    b = enc.conv.bias.detach().cpu().double().requires_grad_(True)
+    a = enc.prelu.weight.detach().cpu().double().requires_grad_(True)
+    Wd = model.weight.detach().cpu().double().requires_grad_(True)
+
+    def f(xx):
+        return torch.nn.functional.prelu(R.gcn_conv_ref(xx, ei, W, b), a)
+    pz, nz = f(x.double()), f(x.double()[perm])
+    sr = torch.sigmoid(pz.mean(0))
+    lr = R.dgi_loss_ref(pz, nz, sr, Wd)
+    lr.backward()
+    assert abs(float(loss) - float(lr)) <= 1e-5 * abs(float(lr))
+    assert rel(enc.conv.weight.grad, W.grad) <= 1e-4
+    assert rel(enc.conv.bias.grad, b.grad) <= 1e-4
+    assert rel(enc.prelu.weight.grad, a.grad) <= 1e-4
+    assert rel(model.weight.grad, Wd.grad) <= 1e-4
+
+
+def test_bad_edge_index_reported():
+    from paccmann_polymer_amd.gcn import CSRGraph
+    ei = torch.tensor([[0, 1], [1, 7]]).cuda()
+    with pytest.raises(IndexError):
+        CSRGraph(ei, 3, check=True)

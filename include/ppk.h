@@ -85,6 +85,29 @@ int ppk_graphreg_dense_bwd(const float* z, int64_t ldz, const int64_t* seg_ptr, 
                            const float* dloss, float* dz, int64_t lddz,
                            void* workspace, size_t ws_bytes, ppk_stream_t stream);
 
+/* ---- K5: sparse (edge-list) graph-regularisation loss ------------------------
+ * BUILD-DEFINED generalisation of graph_loss (graph_constrained_loss.py:25-67) for
+ * relation graphs too large for the dense O(N^3) form: every compared pair is
+ * restricted to an undirected edge set with attribute g[e]; normaliser = max edge
+ * distance.  Equals the reference on a complete edge set.
+ * (rowptr, col, eid) = CSR (ppk_csr_build, no self loops, no normalisation) of the
+ * SYMMETRISED edge list: entry ids e in [0, E) for u->v and E + e for v->u; rev [2E]
+ * maps each entry to its reverse entry.  Anchors [a0, a1) let ranks own node ranges:
+ * dist -> (MAX-all-reduce *max_ptr) -> terms -> (SUM-all-reduce *sum_ptr) -> finish;
+ * bwd yields this rank's partial dz [N, zdim] (reduce-scatter across ranks). */
+size_t ppk_graphreg_sparse_workspace_bytes(int64_t N, int64_t E);
+int ppk_graphreg_sparse_dist(const float* z, int64_t ldz, int64_t N, int64_t zdim, const float* g, int64_t E,
+                             const int64_t* rowptr, const int64_t* col, const int64_t* eid, int64_t a0, int64_t a1,
+                             void* workspace, size_t ws_bytes, ppk_stream_t stream);
+float*  ppk_graphreg_sparse_max_ptr(void* workspace, int64_t N, int64_t E);
+double* ppk_graphreg_sparse_sum_ptr(void* workspace, int64_t N, int64_t E);
+int ppk_graphreg_sparse_terms(int64_t N, int64_t E, const int64_t* rowptr, const int64_t* col, int64_t a0, int64_t a1,
+                              void* workspace, size_t ws_bytes, ppk_stream_t stream);
+int ppk_graphreg_sparse_finish(int64_t N, int64_t E, float* loss, void* workspace, size_t ws_bytes, ppk_stream_t stream);
+int ppk_graphreg_sparse_bwd(const float* z, int64_t ldz, int64_t N, int64_t zdim, int64_t E,
+                            const int64_t* rowptr, const int64_t* col, const int64_t* rev, int64_t a0, int64_t a1,
+                            const float* dloss, float* dz, int64_t lddz, void* workspace, size_t ws_bytes, ppk_stream_t stream);
+
 /* ---- fp32 MFMA GEMM ------------------------------------------------------
  * C[M,N] = alpha * opA(A) . opB(B) + beta * C + bias[N]  (row-major, exact fp32
  * v_mfma_f32_32x32x2_f32).  Replaces the dense contractions the reference

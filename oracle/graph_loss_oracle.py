@@ -56,6 +56,9 @@ def _lib():
         lib.oracle_graph_loss_min_margin.argtypes = [
             f32p, f64p, ctypes.c_int64, ctypes.c_int64]
         lib.oracle_graph_loss_min_margin.restype = ctypes.c_double
+        lib.oracle_graph_loss_sparse.argtypes = [
+            f32p, f64p, ctypes.POINTER(ctypes.c_ubyte), ctypes.c_int64, ctypes.c_int64, f64p]
+        lib.oracle_graph_loss_sparse.restype = ctypes.c_double
         _LIB = lib
     return _LIB
 
@@ -88,6 +91,24 @@ def graph_loss_c(z, g_dists, acc_fp32=True, want_grad=True):
     dz = np.zeros((n, zd), dtype=np.float64) if want_grad else None
     dzp = dz.ctypes.data_as(ctypes.POINTER(ctypes.c_double)) if want_grad else None
     loss = _lib().oracle_graph_loss(zp, gp, n, zd, 1 if acc_fp32 else 0, dzp)
+    return float(loss), dz
+
+
+def graph_loss_sparse_c(z, edge_index, edge_attr):
+    """Sparse generalisation on an undirected edge list [2, E] with
+    attribute [E] -> (loss, dz float64 [N, Z])."""
+    z, zp = _f32(z)
+    n, zd = z.shape
+    ei = np.asarray(edge_index, dtype=np.int64)
+    G = np.zeros((n, n), dtype=np.float64)
+    adj = np.zeros((n, n), dtype=np.uint8)
+    for (u, v), a in zip(ei.T, np.asarray(edge_attr, dtype=np.float64)):
+        G[u, v] = G[v, u] = a
+        adj[u, v] = adj[v, u] = 1
+    dz = np.zeros((n, zd), dtype=np.float64)
+    loss = _lib().oracle_graph_loss_sparse(
+        zp, G.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), adj.ctypes.data_as(ctypes.POINTER(ctypes.c_ubyte)),
+        n, zd, dz.ctypes.data_as(ctypes.POINTER(ctypes.c_double)))
     return float(loss), dz
 
 

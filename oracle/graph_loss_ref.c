@@ -165,3 +165,65 @@ double oracle_graph_loss_min_margin(const float *z, const double *G, int64_t n, 
     free(D);
     return m;
 }
+
+/*
+ * BUILD-DEFINED sparse generalisation (NOT in the reference):
+ * the dense loops above with every compared pair restricted to members of an
+ * undirected edge set (adj[a*n+b] != 0, symmetric, zero diagonal) and the
+ * normaliser taken over edges only.  With a complete edge set it IS the
+ * reference loss (pinned by tests against the golden vectors).
+ * G holds the edge attribute at [a*n+b] for edges.
+ */
+double oracle_graph_loss_sparse(const float *z, const double *G, const unsigned char *adj,
+                                int64_t n, int64_t zdim, double *dz)
+{
+    float *D = (float *)malloc(sizeof(float) * (size_t)(n * n));
+    double *gD = (double *)calloc((size_t)(n * n), sizeof(double));
+    oracle_cdist(z, n, zdim, D);
+    float maxd = 0.0f;
+    for (int64_t a = 0; a < n; ++a)
+        for (int64_t b = 0; b < n; ++b)
+            if (adj[a * n + b] && D[a * n + b] > maxd) maxd = D[a * n + b];
+    double S = 0.0;
+    for (int64_t i = 0; i < n; ++i)
+        for (int64_t j = i + 1; j < n; ++j) {
+            if (!adj[i * n + j]) continue;
+            float d_ij = D[i * n + j];
+            double g_ij = G[i * n + j];
+            for (int64_t r = i; r < n; ++r) {
+                if (r == j || (r != i && !adj[r * n + j])) continue;
+                float dfa;
+                float f = reg_f(sgn_d(g_ij - G[r * n + j]), d_ij, D[r * n + j], &dfa);
+                S += (double)f;
+                gD[i * n + j] += dfa; gD[r * n + j] -= dfa;
+            }
+            for (int64_t c = j; c < n; ++c) {
+                if (c != j && !adj[i * n + c]) continue;
+                float dfa;
+                float f = reg_f(sgn_d(g_ij - (double)D[i * n + c]), d_ij, D[i * n + c], &dfa);
+                S += (double)f;
+                gD[i * n + j] += dfa; gD[i * n + c] -= dfa;
+            }
+        }
+    double inv = 1.0 / (double)maxd;
+    if (dz) {
+        /* ties of the max among edges: both orientations of each tied undirected edge share evenly */
+        int64_t ties = 0;
+        for (int64_t a = 0; a < n * n; ++a) if (adj[a] && D[a] == maxd) ++ties;
+        memset(dz, 0, sizeof(double) * (size_t)(n * zdim));
+        for (int64_t a = 0; a < n; ++a)
+            for (int64_t b = 0; b < n; ++b) {
+                if (a == b || !adj[a * n + b]) continue;
+                double dab = (double)D[a * n + b];
+                if (dab == 0.0) continue;
+                double w = (gD[a * n + b] + gD[b * n + a]) * inv;
+                if (D[a * n + b] == maxd) w += 2.0 * (-S * inv * inv / (double)ties);
+                w /= dab;
+                for (int64_t k = 0; k < zdim; ++k)
+                    dz[a * zdim + k] += w * ((double)z[a * zdim + k] - (double)z[b * zdim + k]);
+            }
+    }
+    free(D);
+    free(gD);
+    return S * inv;
+}

@@ -1,0 +1,161 @@
+"""Sparse (edge-list) graph-regularisation loss — host side of kernel K5.
+
+BUILD-DEFINED generalisation of the reference's dense `graph_loss`
+(`graph_constrained_loss.py:25-67`) to relation graphs that are too large for
+the O(N^3) dense form (BASELINE config 4): all compared pairs are restricted to
+an undirected edge set with attribute `edge_attr` (SURVEY.md Appendix A.4;
+edge-list-form G as in `topo_vae.py:137-140`).  On a complete edge set it equals
+the reference loss.
+
+`SparseRelationGraph` does the one-off integer preprocessing (K6 CSR of the
+symmetrised edge list + reverse-entry map); `graph_loss_sparse` is the
+differentiable op.  With `torch.distributed` initialised and `shard=True`, nodes
+are owned in contiguous ranges: latents are all-gathered, the normaliser is
+MAX-all-reduced, the sum SUM-all-reduced and the partial gradients
+reduce-scattered (RCCL over xGMI).
+"""
+import ctypes
+
+import torch
+import torch.distributed as dist
+
+from . import _C
+from .stack_gru_vae import _ws
+
+_lib = _C.lib
+
+
+class SparseRelationGraph:
+    """edge_index [2, E] int64: each undirected edge ONCE (simple graph, no self
+    loops); edge_attr [E]: graph distance / relation attribute per edge."""
+
+    def __init__(self, edge_index: torch.Tensor, edge_attr: torch.Tensor, num_nodes: int):
+        _C.require_gpu(edge_index, edge_attr)
+        dev = edge_index.device
+        ei = edge_index.to(torch.int64)
+        E, N = int(ei.shape[1]), int(num_nodes)
+        if E < 1 or edge_attr.numel() != E:
+            raise ValueError()
+        self.N, self.E = N, E
+        self.g = edge_attr.to(torch.float32).contiguous()
+        src = torch.cat([ei[0], ei[1]]).contiguous()
+        dst = torch.cat([ei[1], ei[0]]).contiguous()
+        self.rowptr = torch.empty(N + 1, dtype=torch.int64, device=dev)
+        self.col = torch.zeros(2 * E, dtype=torch.int64, device=dev)
+        self.eid = torch.zeros(2 * E, dtype=torch.int64, device=dev)
+        val = torch.empty(2 * E, dtype=torch.float32, device=dev)
+        status = torch.zeros(1, dtype=torch.int32, device=dev)
+        wsb = _lib.ppk_csr_build_workspace_bytes(N, 2 * E)
+        ws = _ws(wsb, dev)
+        # rows keyed by the anchor: entry (anchor = dst, neighbour = src)
+        _C.check(_lib.ppk_csr_build(_C.p(src), _C.p(dst), 2 * E, N, 0, 0, 0, None, _C.p(self.rowptr), _C.p(self.col),
+                                    _C.p(self.eid), _C.p(val), _C.p(status), _C.p(ws), wsb, _C.stream()))
+        if int(status.item()) != 0:
+            raise IndexError('edge_index holds a node id outside [0, num_nodes)')
+        pos_of = torch.empty(2 * E, dtype=torch.int64, device=dev)
+        pos_of[self.eid] = torch.arange(2 * E, dtype=torch.int64, device=dev)
+        self.rev = pos_of[(self.eid + E) % (2 * E)].contiguous()
+
+
+class _SparseGraphLoss(torch.autograd.Function):
+
+    @staticmethod
+    def forward(ctx, z, graph, a0, a1, group):
+        _C.require_gpu(z)
+        z = z.contiguous()
+        N, Z = z.shape
+        E = graph.E
+        dev = z.device
+        wsb = _lib.ppk_graphreg_sparse_workspace_bytes(N, E)
+        ws = _ws(wsb, dev)
+        st = _C.stream()
+        _C.check(_lib.ppk_graphreg_sparse_dist(_C.p(z), z.stride(0), N, Z, _C.p(graph.g), E, _C.p(graph.rowptr),
+                                               _C.p(graph.col), _C.p(graph.eid), a0, a1, _C.p(ws), wsb, st))
+        base = ws.data_ptr()
+        if group is not False:
+            off = _lib.ppk_graphreg_sparse_max_ptr(_C.p(ws), N, E) - base
+            m = ws[off:off + 4].view(torch.float32)
+            dist.all_reduce(m, op=dist.ReduceOp.MAX, group=group)
+        _C.check(_lib.ppk_graphreg_sparse_terms(N, E, _C.p(graph.rowptr), _C.p(graph.col), a0, a1, _C.p(ws), wsb, st))
+        if group is not False:
+            off = _lib.ppk_graphreg_sparse_sum_ptr(_C.p(ws), N, E) - base
+            s = ws[off:off + 8].view(torch.float64)
+            dist.all_reduce(s, op=dist.ReduceOp.SUM, group=group)
+        loss = torch.empty(1, dtype=torch.float32, device=dev)
+        _C.check(_lib.ppk_graphreg_sparse_finish(N, E, _C.p(loss), _C.p(ws), wsb, st))
+        ctx.save_for_backward(z, ws)
+        ctx.graph, ctx.range, ctx.wsb = graph, (a0, a1), wsb
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, dloss):
+        z, ws = ctx.saved_tensors
+        g = ctx.graph
+        a0, a1 = ctx.range
+        N, Z = z.shape
+        dl = dloss.to(torch.float32).reshape(1).contiguous()
+        dz = torch.empty_like(z)
+        _C.check(_lib.ppk_graphreg_sparse_bwd(_C.p(z), z.stride(0), N, Z, g.E, _C.p(g.rowptr), _C.p(g.col), _C.p(g.rev),
+                                              a0, a1, _C.p(dl), _C.p(dz), dz.stride(0), _C.p(ws), ctx.wsb, _C.stream()))
+        return dz, None, None, None, None
+
+
+class _AllGatherRows(torch.autograd.Function):
+    """z_full = all_gather(z_local) (C2); backward = reduce_scatter(SUM) of the partial gradients (C3)."""
+
+    @staticmethod
+    def forward(ctx, z_local, counts, group):
+        ctx.counts, ctx.group = counts, group
+        rank = dist.get_rank(group)
+        # all_gather wants equal shapes: pad every shard to the largest one
+        cmax = max(counts)
+        mine = z_local.contiguous()
+        if mine.shape[0] < cmax:
+            mine = torch.cat([mine, mine.new_zeros(cmax - mine.shape[0], mine.shape[1])])
+        parts = [torch.empty_like(mine) for _ in counts]
+        dist.all_gather(parts, mine, group=group)
+        ctx.rank = rank
+        return torch.cat([p[:c] for p, c in zip(parts, counts)], dim=0)
+
+    @staticmethod
+    def backward(ctx, dz_full):
+        parts = [p.contiguous() for p in torch.split(dz_full, ctx.counts, dim=0)]
+        if dist.get_backend(ctx.group) == 'nccl':
+            cmax = max(ctx.counts)
+            padded = [p if p.shape[0] == cmax else torch.cat([p, p.new_zeros(cmax - p.shape[0], p.shape[1])]) for p in parts]
+            out = torch.empty_like(padded[0])
+            dist.reduce_scatter(out, padded, op=dist.ReduceOp.SUM, group=ctx.group)
+            out = out[:ctx.counts[ctx.rank]]
+        else:                                   # gloo (CPU-side tests) has no reduce_scatter
+            full = dz_full.contiguous().clone()
+            dist.all_reduce(full, op=dist.ReduceOp.SUM, group=ctx.group)
+            out = torch.split(full, ctx.counts, dim=0)[ctx.rank].contiguous()
+        return out, None, None
+
+
+def node_ranges(num_nodes: int, world: int):
+    """Contiguous node ownership: rank r owns [starts[r], starts[r+1])."""
+    base, rem = divmod(num_nodes, world)
+    counts = [base + (1 if r < rem else 0) for r in range(world)]
+    starts = [0]
+    for c in counts:
+        starts.append(starts[-1] + c)
+    return starts, counts
+
+
+def graph_loss_sparse(z, graph: SparseRelationGraph, shard: bool = False, group=None):
+    """loss = (1 / max_e D_e) * sum over anchors of the column / row raster terms
+    restricted to `graph`'s edges.  `shard=False`: `z` is the full [N, Z] latent
+    matrix.  `shard=True` (torch.distributed initialised): `z` holds this rank's
+    contiguous node range; returns the GLOBAL loss on every rank and back-propagates
+    the complete local gradient."""
+    if not shard:
+        if z.shape[0] != graph.N:
+            raise ValueError()
+        return _SparseGraphLoss.apply(z.to(torch.float32), graph, 0, graph.N, False)
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    starts, counts = node_ranges(graph.N, world)
+    if z.shape[0] != counts[rank]:
+        raise ValueError()
+    z_full = _AllGatherRows.apply(z.to(torch.float32), counts, group)
+    return _SparseGraphLoss.apply(z_full, graph, starts[rank], starts[rank + 1], group)

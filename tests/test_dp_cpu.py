@@ -1,0 +1,122 @@
+"""Data-parallel host logic on CPU (gloo, world_size 2): bundle sharding, the
+loss weighting that makes N-rank == 1-rank on the concatenated batch, the flat
+gradient all-reduce, and the all-gather / reduce-scatter autograd op.  The compute
+is injected from the oracle (CPU restatement) — the HIP kernels need a GPU."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+from torch.nn.utils.rnn import pack_sequence
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+PARAMS = dict(vocab_size=20, embedding_size=8, rnn_cell_size=16, n_layers=2, stack_width=4, stack_depth=4,
+              latent_dim=6, dropout=0.0, padding_index=0)
+
+
+def make_bundles(seed, n_bundles):
+    rng = np.random.default_rng(seed)
+    out = []
+    for _ in range(n_bundles):
+        n = int(rng.integers(3, 7))
+        seqs = [torch.tensor(np.concatenate([[2], rng.integers(4, 20, size=int(rng.integers(2, 8))), [3]])) for _ in range(n)]
+        a = np.triu(rng.integers(0, 3, size=(n, n)).astype(np.float64), 1)
+        out.append((seqs, a + a.T, torch.tensor(rng.standard_normal((n, PARAMS['latent_dim'])), dtype=torch.float32)))
+    return out
+
+
+def local_losses(vae, bundles):
+    """decoder loss (mean over this shard's tokens) and sum of bundle graph losses, as autograd tensors."""
+    from oracle import stackgru_ref as R
+    from oracle import graph_loss_oracle as O
+    seqs = [s for b in bundles for s in b[0]]
+    eps = torch.cat([b[2] for b in bundles])
+    enc = pack_sequence(seqs, enforce_sorted=False)
+    tgt = pack_sequence([torch.cat([s[1:], torch.tensor([0])]) for s in seqs], enforce_sorted=False)
+    dec_loss, mu, logvar, z = R.train_step_ref(vae, enc, enc, tgt, eps)
+    z = z.squeeze(0)
+    sizes = [len(b[0]) for b in bundles]
+    gl, dz = O.graph_loss_segmented_c(z.detach().numpy(), [b[1] for b in bundles], sizes, acc_fp32=False)
+    gr = (z * torch.tensor(dz, dtype=torch.float32)).sum()
+    gr = gr - gr.detach() + gl                      # value = oracle loss, gradient = oracle dz
+    n_valid = sum(len(s) for s in seqs) - len(seqs)
+    return dec_loss, gr, n_valid
+
+
+def _rank_main(rank, world, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT='29533', RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from oracle import stackgru_ref as R
+        from paccmann_polymer_amd.distributed import GradSync, global_token_count, shard_bundles
+        from paccmann_polymer_amd.graph_loss_sparse import _AllGatherRows, node_ranges
+        torch.manual_seed(0)
+        vae = R.TeacherVAERef(R.StackGRUEncoderRef(PARAMS), R.StackGRUDecoderRef(PARAMS))
+        bundles = make_bundles(1, 5)
+        mine = [bundles[i] for i in shard_bundles(len(bundles), rank, world)]
+        dec, gr, n_valid = local_losses(vae, mine)
+        total = global_token_count(n_valid)
+        params = list(vae.parameters())
+        flat = torch.zeros(sum(p.numel() for p in params))
+        (dec * (n_valid / total) + 0.7 * gr).backward()
+        off = 0
+        for p in params:
+            flat[off:off + p.numel()] = p.grad.reshape(-1)
+            off += p.numel()
+        GradSync(flat)()
+        # all-gather / reduce-scatter autograd op on uneven shards
+        starts, counts = node_ranges(7, world)
+        zl = torch.arange(counts[rank] * 3, dtype=torch.float32).reshape(-1, 3) + 100 * rank
+        zl.requires_grad_(True)
+        full = _AllGatherRows.apply(zl, counts, None)
+        w = torch.arange(21, dtype=torch.float32).reshape(7, 3) * (rank + 1)
+        (full * w).sum().backward()
+        q.put((rank, flat.numpy(), total, full.detach().numpy(), zl.grad.numpy()))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_step_equals_single_rank_on_concatenated_batch():
+    from oracle import stackgru_ref as R
+    from paccmann_polymer_amd.graph_loss_sparse import node_ranges
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_rank_main, args=(r, 2, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in procs], key=lambda r: r[0])
+    for p in procs:
+        p.join(30)
+        assert p.exitcode == 0
+    # single process on the concatenated batch (same bundle order as rank 0's then rank 1's shards is irrelevant:
+    # the decoder loss is a token mean and the graph loss a sum over bundles)
+    torch.manual_seed(0)
+    vae = R.TeacherVAERef(R.StackGRUEncoderRef(PARAMS), R.StackGRUDecoderRef(PARAMS))
+    bundles = make_bundles(1, 5)
+    dec, gr, n_valid = local_losses(vae, bundles)
+    (dec + 0.7 * gr).backward()
+    want = torch.cat([p.grad.reshape(-1) for p in vae.parameters()]).numpy()
+    assert res[0][2] == res[1][2] == n_valid
+    for r in res:
+        assert np.allclose(r[1], want, rtol=2e-4, atol=2e-6)
+    assert np.array_equal(res[0][1], res[1][1])             # identical on both ranks after the all-reduce
+    # all-gather forward / reduce-scatter backward
+    starts, counts = node_ranges(7, 2)
+    full_want = np.concatenate([np.arange(counts[r] * 3, dtype=np.float32).reshape(-1, 3) + 100 * r for r in range(2)])
+    wsum = np.arange(21, dtype=np.float32).reshape(7, 3) * 3          # (rank0: x1) + (rank1: x2)
+    for r in res:
+        assert np.array_equal(r[3], full_want)
+        assert np.array_equal(r[4], wsum[starts[r[0]]:starts[r[0] + 1]])
+
+
+def test_shard_bundles_is_a_partition():
+    from paccmann_polymer_amd.distributed import shard_bundles
+    for world in (1, 2, 3, 8):
+        got = sorted(i for r in range(world) for i in shard_bundles(37, r, world))
+        assert got == list(range(37))

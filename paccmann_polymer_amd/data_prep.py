@@ -155,3 +155,40 @@ def relabel_bundle(shortlist):
             edges.append([pos[u], pos[v]])
     ei = np.asarray(edges, dtype=np.int64).reshape(-1, 2).T
     return order, ei
+
+
+class Data:
+    """Minimal stand-in for torch_geometric.data.Data as the reference uses it
+    (`data.x` list of token tensors, `data.edge_index` [2, E], `data.num_nodes`)."""
+
+    def __init__(self, x=None, edge_index=None, num_nodes=None, **kwargs):
+        self.x = x
+        self.edge_index = edge_index
+        self.num_nodes = num_nodes if num_nodes is not None else (len(x) if x is not None else None)
+        for k, v in kwargs.items():
+            setattr(self, k, v)
+
+
+def load_data(filename, smiles_language, max_close_neighbors: int = 5, max_total_bundle: int = 20) -> List[Data]:
+    """Reference utils.py:101-198: one 2-hop bundle per node of the relation graph in
+    the JSON file (`smiles2nodes`, `edgelist`), sampled with the global numpy RNG.
+    `smiles_language` needs `smiles_to_token_indexes(str) -> list[int]`."""
+    import json
+    with open(filename, 'r') as f:
+        raw = json.load(f)
+    nodes2smiles = {v: k for k, v in raw['smiles2nodes'].items()}
+    adj = {}
+    for u, v in raw['edgelist']:            # nx.from_edgelist: adjacency in insertion order, duplicates merged
+        adj.setdefault(u, [])
+        adj.setdefault(v, [])
+        if v not in adj[u]:
+            adj[u].append(v)
+            if u != v:
+                adj[v].append(u)
+    data = []
+    for root in range(len(adj)):
+        shortlist = sample_bundle(lambda x: adj[x], root, max_close_neighbors, max_total_bundle)
+        labels, edge_index = relabel_bundle(shortlist)
+        x = [torch.tensor(smiles_language.smiles_to_token_indexes(nodes2smiles[l])) for l in labels]
+        data.append(Data(x=x, edge_index=torch.tensor(edge_index), num_nodes=len(x)))
+    return data

@@ -132,34 +132,41 @@ int ppk_gemm_f32(int transA, int transB, int64_t M, int64_t N, int64_t K, float 
  * (TeacherVAE.encode) and :168 (TeacherVAE.decode); semantics SURVEY.md
  * Appendix B.  batch_sizes_host is a HOST array [T] (PackedSequence.batch_sizes);
  * w_ih / w_hh / b_ih / b_hh are HOST arrays of L device pointers
- * (nn.GRU weight_ih_l{k} [3H, I_k], weight_hh_l{k} [3H, H], gate order r|z|n);
- * ld_wih0 is the row stride of w_ih[0] (>= E + W); wcs [3+W, H] / bcs [3+W] are
+ * (nn.GRU weight_ih_l{k} [3H, H] and bias_ih_l{k} for k >= 1 — entry 0 is not read —,
+ * weight_hh_l{k} [3H, H], bias_hh_l{k}; gate order r|z|n).  The layer-0 input product
+ * is split: table [V, 3H] = embedding.weight . weight_ih_l0[:, :E]^T + bias_ih_l0 (a
+ * lookup per token, hoisted out of the time loop) and wx0s [3H, ks] = weight_ih_l0[:, E:E+W]
+ * zero padded to ks = W rounded up to 32.  wcs [3+W, H] / bcs [3+W] are
  * stack_controls_layer rows 0..2 followed by stack_input_layer; h0 [L, B, H].
+ * H must be a multiple of 32 (the host side pads with zero units); ldcs = 3+W rounded up to 32.
+ * Per step: stack update, then one MFMA GEMM launch per layer with the GRU gate math in
+ * its epilogue (plus the recurrent products needed by the next step).
  * Saved activations (caller-allocated, consumed by the backward):
- *   X [NT, ldx], Hs / HP [L, NT, H], gates [L, NT, 4H], S [NT, D, W], CS [NT, ldcs].
+ *   XS [NT, ks] (stack top), Hs / HP [L, NT, H], gates [L, NT, 4H], S [NT, D, W], CS [NT, ldcs].
  */
-size_t ppk_stackgru_seq_fwd_workspace_bytes(int64_t B, int64_t H, int64_t W);
+size_t ppk_stackgru_seq_fwd_workspace_bytes(int64_t B, int64_t H, int64_t L, int64_t W);
 int ppk_stackgru_seq_fwd(int64_t T, const int64_t* batch_sizes_host, int64_t B, int64_t NT,
-                         int64_t V, int64_t E, int64_t H, int64_t L, int64_t W, int64_t D,
-                         const int64_t* tokens, const float* emb,
-                         const float* const* w_ih, int64_t ld_wih0, const float* const* w_hh,
+                         int64_t V, int64_t H, int64_t L, int64_t W, int64_t D,
+                         const int64_t* tokens, const float* table, const float* wx0s, int64_t ks,
+                         const float* const* w_ih, const float* const* w_hh,
                          const float* const* b_ih, const float* const* b_hh,
                          const float* wcs, const float* bcs, const float* h0,
-                         float* X, int64_t ldx, float* Hs, float* HP, float* gates, float* S,
+                         float* XS, float* Hs, float* HP, float* gates, float* S,
                          float* CS, int64_t ldcs, void* workspace, size_t ws_bytes, ppk_stream_t stream);
 /* dHtop [NT, H] = gradient at the top layer's output of every step.  Outputs:
- * dX [NT, ldx], DGI / DGH [L, NT, 3H] (gate pre-activation gradients of the
- * input / hidden side), DCS [NT, ldcs], dh0 [L, B, H].  Weight gradients are
- * single GEMMs over these: dW_ih = DGI^T In, dW_hh = DGH^T HP, dWcs = DCS^T HP[L-1].
- * The backward takes the weights TRANSPOSED (host arrays of L device pointers
- * w_ih_t[l] [I_l, 3H], w_hh_t[l] [H, 3H]; wcs_t [H, ldcs]) so that the per-step
- * data-gradient GEMMs read k-contiguous operands. */
-size_t ppk_stackgru_seq_bwd_workspace_bytes(int64_t B, int64_t H, int64_t W, int64_t D);
+ * dXS [NT, ks] (gradient of the stack top fed to layer 0), DGI / DGH [L, NT, 3H] (gate
+ * pre-activation gradients of the input / hidden side), DCS [NT, ldcs], dh0 [L, B, H].
+ * Weight gradients are single GEMMs over these: dW_ih[l>=1] = DGI^T Hs[l-1], dW_ih0[:, E:] = DGI0^T XS,
+ * dtable = rows of DGI0 summed per token, dW_hh = DGH^T HP, dWcs = DCS^T HP[L-1].
+ * The backward takes the weights TRANSPOSED (host arrays of L device pointers:
+ * w_ih_t[0] [W, 3H] = stack columns of weight_ih_l0, w_ih_t[l>=1] [H, 3H], w_hh_t[l] [H, 3H];
+ * wcs_t [H, ldcs] zero padded) so that the per-step data-gradient GEMMs read k-contiguous operands. */
+size_t ppk_stackgru_seq_bwd_workspace_bytes(int64_t B, int64_t W, int64_t D);
 int ppk_stackgru_seq_bwd(int64_t T, const int64_t* batch_sizes_host, int64_t B, int64_t NT,
-                         int64_t V, int64_t E, int64_t H, int64_t L, int64_t W, int64_t D,
+                         int64_t H, int64_t L, int64_t W, int64_t D,
                          const float* const* w_ih_t, const float* const* w_hh_t, const float* wcs_t,
                          const float* HP, const float* gates, const float* S, const float* CS, int64_t ldcs,
-                         const float* dHtop, float* dX, int64_t ldx, float* DGI, float* DGH, float* DCS,
+                         const float* dHtop, float* dXS, int64_t ks, float* DGI, float* DGH, float* DCS,
                          float* dh0, void* workspace, size_t ws_bytes, ppk_stream_t stream);
 
 /* ---- row gather / scatter, column sums, embedding gradient ----------------

@@ -80,6 +80,28 @@ __device__ __forceinline__ void gload_xc(f32x4 (&reg)[ROWS / 32], const float* _
         reg[i] = v;
     }
 }
+// unguarded variants for interior tiles (full rows, K a multiple of BK, float4-aligned operands)
+template <int ROWS>
+__device__ __forceinline__ void gload_kc_fast(f32x4 (&reg)[ROWS / 32], const float* __restrict__ src, long long ld,
+                                              int row0, int k0, int tid)
+{
+#pragma unroll
+    for (int i = 0; i < ROWS / 32; ++i) {
+        const int idx = tid + 256 * i;
+        reg[i] = *reinterpret_cast<const f32x4*>(src + (long long)(row0 + (idx >> 3)) * ld + k0 + ((idx & 7) << 2));
+    }
+}
+template <int ROWS>
+__device__ __forceinline__ void gload_xc_fast(f32x4 (&reg)[ROWS / 32], const float* __restrict__ src, long long ld,
+                                              int x0, int k0, int tid)
+{
+    constexpr int QPR = ROWS / 4;
+#pragma unroll
+    for (int i = 0; i < ROWS / 32; ++i) {
+        const int idx = tid + 256 * i;
+        reg[i] = *reinterpret_cast<const f32x4*>(src + (long long)(k0 + idx / QPR) * ld + x0 + ((idx % QPR) << 2));
+    }
+}
 // ---- registers -> LDS --------------------------------------------------------
 template <int ROWS>
 __device__ __forceinline__ void sstore_kc(float* lds, const f32x4 (&reg)[ROWS / 32], int tid)
@@ -128,9 +150,10 @@ struct GemmArgs {
     float* slabs;        // [ksplit][M][N] when ksplit > 1
     int a_vec, b_vec;    // operand base 16-B aligned and leading dimension % 4 == 0 -> float4 loads
 };
-// up to two independent problems per launch (grid.z picks the problem): the two
-// gate GEMMs of a GRU layer-step share one launch so the grid fills the chip.
-struct GemmBatch { GemmArgs p[2]; int grouped; };
+// up to MAX_GROUP independent problems per launch (grid.z picks the problem): the
+// hidden-side gate GEMMs of all GRU layers of a step share one launch so the grid fills the chip.
+constexpr int MAX_GROUP = 4;
+struct GemmBatch { GemmArgs p[MAX_GROUP]; int grouped; };
 
 template <int BM, int BN, bool A_KC, bool B_KC>
 __global__ __launch_bounds__(256) void k_gemm(const GemmBatch gb)
@@ -158,11 +181,20 @@ __global__ __launch_bounds__(256) void k_gemm(const GemmBatch gb)
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     f32x4 ra[BM / 32], rb[BN / 32];
+    // interior tile: no row / k guards, float4 loads (block-uniform choice)
+    const bool fast = g.a_vec && g.b_vec && m0 + BM <= g.M && n0 + BN <= g.N && ((kend - kbeg) % BK) == 0;
     auto gload = [&](int k0) {
-        if constexpr (A_KC) gload_kc<BM>(ra, g.A, g.lda, m0, g.M, k0, kend, tid, g.a_vec);
-        else                gload_xc<BM>(ra, g.A, g.lda, m0, g.M, k0, kend, tid, g.a_vec);
-        if constexpr (B_KC) gload_kc<BN>(rb, g.B, g.ldb, n0, g.N, k0, kend, tid, g.b_vec);
-        else                gload_xc<BN>(rb, g.B, g.ldb, n0, g.N, k0, kend, tid, g.b_vec);
+        if (fast) {
+            if constexpr (A_KC) gload_kc_fast<BM>(ra, g.A, g.lda, m0, k0, tid);
+            else                gload_xc_fast<BM>(ra, g.A, g.lda, m0, k0, tid);
+            if constexpr (B_KC) gload_kc_fast<BN>(rb, g.B, g.ldb, n0, k0, tid);
+            else                gload_xc_fast<BN>(rb, g.B, g.ldb, n0, k0, tid);
+        } else {
+            if constexpr (A_KC) gload_kc<BM>(ra, g.A, g.lda, m0, g.M, k0, kend, tid, g.a_vec);
+            else                gload_xc<BM>(ra, g.A, g.lda, m0, g.M, k0, kend, tid, g.a_vec);
+            if constexpr (B_KC) gload_kc<BN>(rb, g.B, g.ldb, n0, g.N, k0, kend, tid, g.b_vec);
+            else                gload_xc<BN>(rb, g.B, g.ldb, n0, g.N, k0, kend, tid, g.b_vec);
+        }
     };
     gload(kbeg);
     for (int k0 = kbeg; k0 < kend; k0 += BK) {
@@ -268,7 +300,7 @@ Plan make_plan(long long M, long long N, long long K, bool allow_split)
     else pl.tile = 0;
     const long long blocks = pl.tile == 2 ? b22 : (pl.tile == 1 ? b21 : b11);
     if (allow_split && blocks < 256 && K >= 2048) {
-        long long want = cdiv(512, blocks);
+        long long want = cdiv(768, blocks);                 // three resident blocks per CU
         long long maxs = K / 1024;
         long long s = want < maxs ? want : maxs;
         if (s > 64) s = 64;
@@ -334,8 +366,16 @@ int gemm(int transA, int transB, int64_t M, int64_t N, int64_t K, float alpha,
     gb.grouped = 0;
     GemmArgs& g = gb.p[0];
     fill_args(g, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, bias);
-    gb.p[1] = g;
     Plan pl = make_plan(M, N, K, ws != nullptr);
+    if (a_kc && b_kc && alpha == 1.f && pl.ksplit == 1 && M <= 0x7fffffff && gemm_nt_fast_ok(K, A, lda, B, ldb)) {
+        // LDS-DMA staged NT kernel (ppk_gemm_nt.hip)
+        NtProblem p{};
+        p.A = A; p.B = B; p.lda = lda; p.ldb = ldb;
+        p.M = (int)M; p.N = (int)N; p.K = (int)K; p.a_rows = (int)M;
+        p.epi = NT_STORE; p.H = 0;
+        p.C = C; p.ldc = ldc; p.bias = bias; p.beta = beta;
+        return gemm_nt64(&p, 1, stream);
+    }
     if (pl.ksplit > 1) {
         const size_t need = sizeof(float) * (size_t)M * (size_t)N * (size_t)pl.ksplit;
         if (need <= ws_bytes) {
@@ -355,27 +395,30 @@ int gemm(int transA, int transB, int64_t M, int64_t N, int64_t K, float alpha,
     return PPK_OK;
 }
 
-// Two independent NT problems (C_i = alpha_i A_i B_i^T + beta_i C_i + bias_i) in ONE launch.
-int gemm_nt_pair(const GemmProblem& p0, const GemmProblem& p1, hipStream_t stream)
+// Up to MAX_GROUP independent NT problems (C_i = alpha_i A_i B_i^T + beta_i C_i + bias_i) in ONE launch.
+int gemm_nt_group(const GemmProblem* ps, int count, hipStream_t stream)
 {
-    const GemmProblem* ps[2] = {&p0, &p1};
+    if (count < 1 || count > MAX_GROUP) PPK_FAIL(PPK_ERR_UNSUP, "gemm_nt_group: 1..%d problems", MAX_GROUP);
     GemmBatch gb;
     gb.grouped = 1;
     double flops = 0;
-    long long maxMN = 0;
-    for (int i = 0; i < 2; ++i) {
-        const GemmProblem& p = *ps[i];
-        if (p.M == 0 || p.N == 0) PPK_FAIL(PPK_ERR_SHAPE, "gemm_nt_pair: empty problem");
+    for (int i = 0; i < count; ++i) {
+        const GemmProblem& p = ps[i];
+        if (p.M == 0 || p.N == 0) PPK_FAIL(PPK_ERR_SHAPE, "gemm_nt_group: empty problem");
         int rc = check_problem(0, 1, p.M, p.N, p.K, p.A, p.lda, p.B, p.ldb, p.C, p.ldc);
         if (rc) return rc;
         fill_args(gb.p[i], p.M, p.N, p.K, p.alpha, p.A, p.lda, p.B, p.ldb, p.beta, p.C, p.ldc, p.bias);
         flops += 2.0 * (double)p.M * (double)p.N * (double)p.K;
-        maxMN = maxMN > p.M * p.N ? maxMN : p.M * p.N;
     }
-    (void)maxMN;
-    dispatch(gb, 2, 0, true, true, flops, stream);
-    PPK_CHECK_LAUNCH("k_gemm(pair)");
+    dispatch(gb, count, 0, true, true, flops, stream);
+    PPK_CHECK_LAUNCH("k_gemm(group)");
     return PPK_OK;
+}
+
+int gemm_nt_pair(const GemmProblem& p0, const GemmProblem& p1, hipStream_t stream)
+{
+    const GemmProblem ps[2] = {p0, p1};
+    return gemm_nt_group(ps, 2, stream);
 }
 
 }  // namespace ppk

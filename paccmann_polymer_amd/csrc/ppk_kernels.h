@@ -22,6 +22,30 @@ struct GemmProblem {
 };
 // two independent NT problems in one launch (64x64 tiles, grid.z = problem)
 int gemm_nt_pair(const GemmProblem& p0, const GemmProblem& p1, hipStream_t stream);
+// up to 4 independent NT problems in one launch
+int gemm_nt_group(const GemmProblem* ps, int count, hipStream_t stream);
+
+// ---- NT GEMMs with LDS-DMA staging and fused GRU epilogues (ppk_gemm_nt.hip) ----
+//   acc[M,N] = A[M,K] . B[N,K]^T ; K % 32 == 0, lda/ldb % 4 == 0, 16-byte aligned operands.
+//   Only the first a_rows rows of A exist: rows >= a_rows contribute acc = 0 (their loads are clamped).
+enum NtEpi { NT_STORE = 0, NT_GRU_FWD = 1, NT_GRU_BWD = 2 };
+constexpr int NT_MAX_GROUP = 4;
+struct NtProblem {
+    const float* A; const float* B; long long lda, ldb;
+    int M, N, K, a_rows;
+    int epi;
+    int H;                       // hidden size (gate layout: N == 3H ; NT_GRU_BWD: N == H)
+    // NT_STORE: C = acc + bias[col] + beta * C
+    float* C; long long ldc; const float* bias; float beta;
+    // NT_GRU_FWD (gate layout): gi = acc + bias (+ table[tok[row]]) ; gh [M,3H] holds W_hh h + b_hh
+    const float* gh; const float* hprev; const int64_t* tok; const float* table;
+    float* hnew; float* hp_out; float* gates_out;          // [M,H], [M,H], [M,4H] = r, z, n, gh_n
+    // NT_GRU_BWD: dh = acc + carry (+ ext) ; writes dgi, dgh [M,3H] and carry = dh * z
+    float* carry; const float* ext; const float* gates_in; const float* hp_in; float* dgi; float* dgh;
+};
+bool gemm_nt_fast_ok(int64_t K, const float* A, int64_t lda, const float* B, int64_t ldb);
+int gemm_nt64(const NtProblem* ps, int count, hipStream_t stream);   // 64 x 64 tiles: NT_STORE, NT_GRU_BWD
+int gemm_ntF(const NtProblem* ps, int count, hipStream_t stream);    // 128 x (3 x 32) gate-layout tiles: NT_STORE, NT_GRU_FWD
 
 
 // ---- opt-in per-kernel timing (HIP events on the launch stream) -------------
@@ -32,6 +56,7 @@ enum ProfKind {
     PK_GEMM_L_XX, PK_GEMM_L_XK, PK_GEMM_L_KX, PK_GEMM_L_KK,          // 128x128 tiles
     PK_STACK_FWD, PK_STACK_BWD, PK_GATE_FWD, PK_GATE_BWD,
     PK_GRAPHREG_TERMS, PK_GRAPHREG_DZ, PK_SPMM, PK_GRAPHREG_SPARSE,
+    PK_GEMM_NT64, PK_GEMM_NTF,
     PK_COUNT
 };
 struct ProfScope {

@@ -16,10 +16,16 @@
 //   Hs    [L, NT, H]  hidden after the step          HP [L, NT, H] hidden before it
 //   gates [L, NT, 4H] r, z, n, (W_hn h + b_hn)
 //   S     [NT, D, W]  stack after the step           CS [NT, ldcs] softmax(3) | tanh(W)
-// The gate contractions are fp32-MFMA GEMMs (ppk_gemm.hip) launched per step:
-// at batch 2048 each is ~3 GFLOP, far above the ~1.5 us kernel boundary, while a
-// persistent LDS-resident-weights kernel would pay a 4-6 us grid barrier per
-// layer-step (MI355X_MICROARCH.md price list) — see DESIGN.md.
+//   XS    [NT, ks]    stack top fed to layer 0 (ks = W rounded up to 32, zero padded)
+// The gate contractions are fp32-MFMA GEMMs (ppk_gemm_nt.hip) launched per step
+// with the GRU gate math fused into their epilogues: at batch 2048 each is
+// 3-6 GFLOP, far above the ~1.5 us kernel boundary, while a persistent
+// LDS-resident-weights kernel would pay a 4-6 us grid barrier per layer-step
+// (MI355X_MICROARCH.md price list) — see DESIGN.md.
+// Per step (forward):   stack update -> cell 0 {K = ks, + table[token]} -> for l >= 1
+// {cell l ; W_hh[l-1] h for the NEXT step} -> {W_hh[L-1] h ; stack heads} for the next step.
+// The embedding half of the layer-0 input product is hoisted out of the time loop:
+// table[v] = emb[v] . W_ih0[:, :E]^T + b_ih0 is a [V, 3H] lookup.
 #include "ppk_common.h"
 #include "ppk_kernels.h"
 #include <vector>
@@ -29,19 +35,6 @@ namespace {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
-
-// X[row, 0:E] = emb[tok[row], :]
-__global__ __launch_bounds__(256) void k_embed(const int64_t* __restrict__ tok, const float* __restrict__ emb,
-                                               int V, int E, long long NT, float* __restrict__ X, long long ldx)
-{
-    const long long total = NT * E;
-    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
-        const long long row = e / E;
-        const int c = (int)(e % E);
-        const long long t = tok[row];
-        X[row * ldx + c] = (t >= 0 && t < V) ? emb[t * E + c] : 0.0f;
-    }
-}
 
 // one block per active row: stack update (Appendix B) + stack top into X
 __global__ __launch_bounds__(256) void k_stack_fwd(const float* __restrict__ csraw, long long ldcs,
@@ -81,75 +74,7 @@ __global__ __launch_bounds__(256) void k_stack_fwd(const float* __restrict__ csr
         sn[i] = v;
         if (d == 0) Xtop[b * ldx + w] = v;
     }
-}
-
-// GRU gate math for one layer-step: rows x H, float4 over H.
-__global__ __launch_bounds__(256) void k_gate_fwd(const float* __restrict__ gi, const float* __restrict__ gh,
-                                                  const float* __restrict__ hprev, int rows, int H,
-                                                  float* __restrict__ hnew, float* __restrict__ hp_out,
-                                                  float* __restrict__ gates)
-{
-    const int H4 = H >> 2;
-    const long long total = (long long)rows * H4;
-    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
-        const long long row = e / H4;
-        const int j = (int)(e % H4) << 2;
-        const float* gir = gi + row * 3 * H;
-        const float* ghr = gh + row * 3 * H;
-        const f32x4 ir = *(const f32x4*)(gir + j), iz = *(const f32x4*)(gir + H + j), in_ = *(const f32x4*)(gir + 2 * H + j);
-        const f32x4 hr = *(const f32x4*)(ghr + j), hz = *(const f32x4*)(ghr + H + j), hn = *(const f32x4*)(ghr + 2 * H + j);
-        const f32x4 hp = *(const f32x4*)(hprev + row * H + j);
-        f32x4 r, z, n, h;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            r[k] = sigmoidf_(ir[k] + hr[k]);
-            z[k] = sigmoidf_(iz[k] + hz[k]);
-            n[k] = tanhf(in_[k] + r[k] * hn[k]);
-            h[k] = (1.0f - z[k]) * n[k] + z[k] * hp[k];
-        }
-        *(f32x4*)(hnew + row * H + j) = h;
-        *(f32x4*)(hp_out + row * H + j) = hp;
-        float* g = gates + row * 4 * H;
-        *(f32x4*)(g + j) = r;
-        *(f32x4*)(g + H + j) = z;
-        *(f32x4*)(g + 2 * H + j) = n;
-        *(f32x4*)(g + 3 * H + j) = hn;
-    }
-}
-
-// backward of the gate math.  dh = carry + ext + dxup ; writes DGI, DGH and carry = dh * z
-__global__ __launch_bounds__(256) void k_gate_bwd(float* __restrict__ carry, const float* __restrict__ ext,
-                                                  const float* __restrict__ dxup, const float* __restrict__ gates,
-                                                  const float* __restrict__ hp, int rows, int H,
-                                                  float* __restrict__ dgi, float* __restrict__ dgh)
-{
-    const int H4 = H >> 2;
-    const long long total = (long long)rows * H4;
-    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
-        const long long row = e / H4;
-        const int j = (int)(e % H4) << 2;
-        f32x4 dh = *(const f32x4*)(carry + row * H + j);
-        if (ext) dh += *(const f32x4*)(ext + row * H + j);
-        if (dxup) dh += *(const f32x4*)(dxup + row * H + j);
-        const float* g = gates + row * 4 * H;
-        const f32x4 r = *(const f32x4*)(g + j), z = *(const f32x4*)(g + H + j);
-        const f32x4 n = *(const f32x4*)(g + 2 * H + j), hn = *(const f32x4*)(g + 3 * H + j);
-        const f32x4 hprev = *(const f32x4*)(hp + row * H + j);
-        f32x4 dr, dz, dn, dnr, c;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            dn[k] = dh[k] * (1.0f - z[k]) * (1.0f - n[k] * n[k]);
-            dz[k] = dh[k] * (hprev[k] - n[k]) * z[k] * (1.0f - z[k]);
-            dr[k] = dn[k] * hn[k] * r[k] * (1.0f - r[k]);
-            dnr[k] = dn[k] * r[k];
-            c[k] = dh[k] * z[k];
-        }
-        float* a = dgi + row * 3 * H;
-        float* b = dgh + row * 3 * H;
-        *(f32x4*)(a + j) = dr;  *(f32x4*)(a + H + j) = dz;  *(f32x4*)(a + 2 * H + j) = dn;
-        *(f32x4*)(b + j) = dr;  *(f32x4*)(b + H + j) = dz;  *(f32x4*)(b + 2 * H + j) = dnr;
-        *(f32x4*)(carry + row * H + j) = c;
-    }
+    for (int w = W + threadIdx.x; w < ldx; w += 256) Xtop[b * ldx + w] = 0.f;      // zero padding of the K operand
 }
 
 __device__ __forceinline__ float block_sum_256(float v, float* red)
@@ -220,17 +145,18 @@ __global__ __launch_bounds__(256) void k_stack_bwd(const float* __restrict__ dS_
         const float s = act[3 + w];
         dcs[3 + w] = a_push * dst[w] * (1.0f - s * s);
     }
+    for (long long w = 3 + W + threadIdx.x; w < ldcs; w += 256) dcs[w] = 0.f;     // zero padding of the K operand
 }
 
-struct SeqDims { int64_t T, B, NT, E, H, L, W, D, V, ldx, ldcs; };
+struct SeqDims { int64_t T, B, NT, H, L, W, D, V, ks, ldcs; };
 
 int check_dims(const SeqDims& d, const int64_t* bs, std::vector<int64_t>& off)
 {
-    if (d.T < 1 || d.B < 1 || d.E < 1 || d.H < 4 || d.L < 1 || d.W < 1 || d.D < 1 || d.V < 1)
+    if (d.T < 1 || d.B < 1 || d.H < 1 || d.L < 1 || d.W < 1 || d.D < 1 || d.V < 1)
         PPK_FAIL(PPK_ERR_SHAPE, "stackgru: non-positive size");
-    if (d.H % 4) PPK_FAIL(PPK_ERR_UNSUP, "stackgru: rnn_cell_size must be a multiple of 4");
-    if (d.ldx < d.E + d.W || d.ldx % 4 || d.ldcs < 3 + d.W || d.ldcs % 4)
-        PPK_FAIL(PPK_ERR_ALIGN, "stackgru: ldx/ldcs must cover E+W / 3+W and be multiples of 4");
+    if (d.H % 32) PPK_FAIL(PPK_ERR_UNSUP, "stackgru: rnn_cell_size must be a multiple of 32 (the host side pads with zero units)");
+    if (d.ks < d.W || d.ks % 32 || d.ldcs < 3 + d.W || d.ldcs % 32)
+        PPK_FAIL(PPK_ERR_ALIGN, "stackgru: ks / ldcs must cover W / 3+W and be multiples of 32");
     if ((size_t)(d.D * d.W + 3 + d.W) * 4 > 60 * 1024) PPK_FAIL(PPK_ERR_UNSUP, "stackgru: stack_depth*stack_width too large for LDS");
     if (!bs) PPK_FAIL(PPK_ERR_NULL, "stackgru: batch_sizes is null");
     off.assign((size_t)d.T + 1, 0);
@@ -242,141 +168,181 @@ int check_dims(const SeqDims& d, const int64_t* bs, std::vector<int64_t>& off)
     return PPK_OK;
 }
 
-inline unsigned grid_for(long long work, int per_block = 256, unsigned cap = 4096)
+ppk::NtProblem nt_store(const float* A, int64_t lda, int64_t M, const float* Bm, int64_t ldb, int64_t N, int64_t K,
+                        float* C, int64_t ldc, const float* bias, float beta, int64_t H)
 {
-    long long b = (work + per_block - 1) / per_block;
-    if (b < 1) b = 1;
-    return (unsigned)(b < cap ? b : cap);
+    ppk::NtProblem p{};
+    p.A = A; p.B = Bm; p.lda = lda; p.ldb = ldb;
+    p.M = (int)M; p.N = (int)N; p.K = (int)K; p.a_rows = (int)M;
+    p.epi = ppk::NT_STORE; p.H = (int)H;
+    p.C = C; p.ldc = ldc; p.bias = bias; p.beta = beta;
+    return p;
 }
 
 }  // namespace
 
 extern "C" {
 
-size_t ppk_stackgru_seq_fwd_workspace_bytes(int64_t B, int64_t H, int64_t W)
+size_t ppk_stackgru_seq_fwd_workspace_bytes(int64_t B, int64_t H, int64_t L, int64_t W)
 {
-    if (B < 1 || H < 1 || W < 1) return 0;
-    const int64_t ldcs = (3 + W + 3) / 4 * 4;
-    return 2 * ppk_align_up(sizeof(float) * (size_t)B * 3 * (size_t)H, 256) + ppk_align_up(sizeof(float) * (size_t)B * (size_t)ldcs, 256);
+    if (B < 1 || H < 1 || L < 1 || W < 1) return 0;
+    const int64_t ldcs = (3 + W + 31) / 32 * 32;
+    return (size_t)L * ppk_align_up(sizeof(float) * (size_t)B * 3 * (size_t)H, 256) + ppk_align_up(sizeof(float) * (size_t)B * (size_t)ldcs, 256);
 }
 
+// table [V, 3H]  = emb . W_ih0[:, :E]^T + b_ih0      (embedding half of the layer-0 input product)
+// wx0s  [3H, ks] = W_ih0[:, E:E+W], zero padded       (stack half)
+// w_ih[l], b_ih[l] are read for l >= 1 only.
 int ppk_stackgru_seq_fwd(int64_t T, const int64_t* batch_sizes_host, int64_t B, int64_t NT,
-                         int64_t V, int64_t E, int64_t H, int64_t L, int64_t W, int64_t D,
-                         const int64_t* tokens, const float* emb,
-                         const float* const* w_ih, int64_t ld_wih0, const float* const* w_hh,
+                         int64_t V, int64_t H, int64_t L, int64_t W, int64_t D,
+                         const int64_t* tokens, const float* table, const float* wx0s, int64_t ks,
+                         const float* const* w_ih, const float* const* w_hh,
                          const float* const* b_ih, const float* const* b_hh,
                          const float* wcs, const float* bcs, const float* h0,
-                         float* X, int64_t ldx, float* Hs, float* HP, float* gates, float* S,
+                         float* XS, float* Hs, float* HP, float* gates, float* S,
                          float* CS, int64_t ldcs, void* workspace, size_t ws_bytes, hipStream_t stream)
 {
-    SeqDims d{T, B, NT, E, H, L, W, D, V, ldx, ldcs};
+    SeqDims d{T, B, NT, H, L, W, D, V, ks, ldcs};
     std::vector<int64_t> off;
     int rc = check_dims(d, batch_sizes_host, off);
     if (rc) return rc;
-    if (!tokens || !emb || !w_ih || !w_hh || !b_ih || !b_hh || !wcs || !bcs || !h0 || !X || !Hs || !HP || !gates || !S || !CS || !workspace)
+    if (!tokens || !table || !wx0s || !w_ih || !w_hh || !b_ih || !b_hh || !wcs || !bcs || !h0 || !XS || !Hs || !HP || !gates || !S || !CS || !workspace)
         PPK_FAIL(PPK_ERR_NULL, "stackgru_seq_fwd: null pointer");
-    if (ws_bytes < ppk_stackgru_seq_fwd_workspace_bytes(B, H, W)) PPK_FAIL(PPK_ERR_WS, "stackgru_seq_fwd: workspace too small");
-    if (ld_wih0 < E + W) PPK_FAIL(PPK_ERR_SHAPE, "stackgru_seq_fwd: ld_wih0 < E + W");
+    if (ws_bytes < ppk_stackgru_seq_fwd_workspace_bytes(B, H, L, W)) PPK_FAIL(PPK_ERR_WS, "stackgru_seq_fwd: workspace too small");
     char* cur = (char*)workspace;
-    float* gi = (float*)ppk_carve(cur, sizeof(float) * (size_t)B * 3 * H);
-    float* gh = (float*)ppk_carve(cur, sizeof(float) * (size_t)B * 3 * H);
+    std::vector<float*> gh((size_t)L);
+    for (int64_t l = 0; l < L; ++l) gh[(size_t)l] = (float*)ppk_carve(cur, sizeof(float) * (size_t)B * 3 * H);
     float* csraw = (float*)ppk_carve(cur, sizeof(float) * (size_t)B * ldcs);
-    const int64_t I0 = E + W;
     const size_t lds_stack = sizeof(float) * (size_t)(3 + W);
+    const int64_t H3 = 3 * H;
 
-    k_embed<<<dim3(grid_for(NT * E)), dim3(256), 0, stream>>>(tokens, emb, (int)V, (int)E, NT, X, ldx);
-    PPK_CHECK_LAUNCH("k_embed");
+    // products of the hidden state entering a step that are needed one step later:
+    //   gh[l] = W_hh[l] h_l + b_hh[l]  and  csraw = [W_c ; W_s] h_{L-1} + b   (rows < M)
+    auto next_step_products = [&](const float* hlast, int64_t M) -> int {
+        const ppk::NtProblem ps[2] = {
+            nt_store(hlast, H, M, w_hh[L - 1], H, H3, H, gh[(size_t)L - 1], H3, b_hh[L - 1], 0.f, H),
+            nt_store(hlast, H, M, wcs, H, 3 + W, H, csraw, ldcs, bcs, 0.f, H)};
+        return ppk::gemm_nt64(ps, 2, stream);
+    };
+    // prologue: the same products of the initial hidden state
+    for (int64_t l = 0; l + 1 < L; ++l) {
+        const ppk::NtProblem p = nt_store(h0 + l * B * H, H, B, w_hh[l], H, H3, H, gh[(size_t)l], H3, b_hh[l], 0.f, H);
+        rc = ppk::gemm_ntF(&p, 1, stream);
+        if (rc) return rc;
+    }
+    rc = next_step_products(h0 + (L - 1) * B * H, B);
+    if (rc) return rc;
+
     for (int64_t t = 0; t < T; ++t) {
         const int64_t Bt = batch_sizes_host[t], o = off[(size_t)t], op = t > 0 ? off[(size_t)t - 1] : 0;
+        const int64_t Bn = t + 1 < T ? batch_sizes_host[t + 1] : 0;
         auto hprev = [&](int64_t l) { return t == 0 ? h0 + l * B * H : Hs + (l * NT + op) * H; };
-        rc = ppk::gemm(0, 1, Bt, 3 + W, H, 1.f, hprev(L - 1), H, wcs, H, 0.f, csraw, ldcs, bcs, nullptr, 0, stream);
-        if (rc) return rc;
         { ppk::ProfScope prof(ppk::PK_STACK_FWD, 8.0 * (double)Bt * D * W, stream);
         k_stack_fwd<<<dim3((unsigned)Bt), dim3(256), lds_stack, stream>>>(
-            csraw, ldcs, t == 0 ? nullptr : S + op * D * W, S + o * D * W, CS + o * ldcs, X + o * ldx + E, ldx, (int)D, (int)W); }
+            csraw, ldcs, t == 0 ? nullptr : S + op * D * W, S + o * D * W, CS + o * ldcs, XS + o * ks, ks, (int)D, (int)W); }
         PPK_CHECK_LAUNCH("k_stack_fwd");
         for (int64_t l = 0; l < L; ++l) {
-            const float* in = l == 0 ? X + o * ldx : Hs + ((l - 1) * NT + o) * H;
-            const int64_t Il = l == 0 ? I0 : H, ldin = l == 0 ? ldx : H;
-            // both gate GEMMs of the layer-step in one launch
-            const ppk::GemmProblem pi{Bt, 3 * H, Il, 1.f, in, ldin, w_ih[l], l == 0 ? ld_wih0 : H, 0.f, gi, 3 * H, b_ih[l]};
-            const ppk::GemmProblem ph{Bt, 3 * H, H, 1.f, hprev(l), H, w_hh[l], H, 0.f, gh, 3 * H, b_hh[l]};
-            rc = ppk::gemm_nt_pair(pi, ph, stream);
+            ppk::NtProblem ps[2];
+            int n = 0;
+            ppk::NtProblem& c = ps[n++];
+            c = ppk::NtProblem{};
+            if (l == 0) { c.A = XS + o * ks; c.lda = ks; c.K = (int)ks; c.B = wx0s; c.ldb = ks; c.tok = tokens + o; c.table = table; c.bias = nullptr; }
+            else        { c.A = Hs + ((l - 1) * NT + o) * H; c.lda = H; c.K = (int)H; c.B = w_ih[l]; c.ldb = H; c.bias = b_ih[l]; }
+            c.M = (int)Bt; c.N = (int)H3; c.a_rows = (int)Bt; c.H = (int)H; c.epi = ppk::NT_GRU_FWD;
+            c.gh = gh[(size_t)l]; c.hprev = hprev(l);
+            c.hnew = Hs + (l * NT + o) * H; c.hp_out = HP + (l * NT + o) * H; c.gates_out = gates + (l * NT + o) * 4 * H;
+            // the layer below has just produced h_{l-1,t}: its recurrent product for step t+1 shares this launch
+            if (l > 0 && Bn > 0)
+                ps[n++] = nt_store(Hs + ((l - 1) * NT + o) * H, H, Bn, w_hh[l - 1], H, H3, H, gh[(size_t)l - 1], H3, b_hh[l - 1], 0.f, H);
+            rc = ppk::gemm_ntF(ps, n, stream);
             if (rc) return rc;
-            { ppk::ProfScope prof(ppk::PK_GATE_FWD, 4.0 * 13 * (double)Bt * H, stream);
-            k_gate_fwd<<<dim3(grid_for(Bt * H / 4)), dim3(256), 0, stream>>>(
-                gi, gh, hprev(l), (int)Bt, (int)H, Hs + (l * NT + o) * H, HP + (l * NT + o) * H, gates + (l * NT + o) * 4 * H); }
-            PPK_CHECK_LAUNCH("k_gate_fwd");
+        }
+        if (Bn > 0) {
+            rc = next_step_products(Hs + ((L - 1) * NT + o) * H, Bn);
+            if (rc) return rc;
         }
     }
     return PPK_OK;
 }
 
-size_t ppk_stackgru_seq_bwd_workspace_bytes(int64_t B, int64_t H, int64_t W, int64_t D)
+size_t ppk_stackgru_seq_bwd_workspace_bytes(int64_t B, int64_t W, int64_t D)
 {
-    if (B < 1 || H < 1 || W < 1 || D < 1) return 0;
-    return 2 * ppk_align_up(sizeof(float) * (size_t)B * (size_t)D * (size_t)W, 256) + ppk_align_up(sizeof(float) * (size_t)B * (size_t)H, 256);
+    if (B < 1 || W < 1 || D < 1) return 0;
+    return 2 * ppk_align_up(sizeof(float) * (size_t)B * (size_t)D * (size_t)W, 256);
 }
 
 // dHtop [NT, H]: gradient arriving at the top layer's output of every step
 // (decoder: from the logits; encoder: zero except each sequence's last step).
-// Outputs: dX [NT, ldx], DGI / DGH [L, NT, 3H], DCS [NT, ldcs], dh0 [L, B, H].
-// The weight gradients are single large GEMMs over these (host side).
-// Weights arrive TRANSPOSED (w_ih_t[l] [I_l, 3H], w_hh_t[l] [H, 3H], wcs_t [H, ldcs])
-// so that every per-step data-gradient GEMM reads k-contiguous operands.
+// Outputs: dXS [NT, ks] (gradient of the stack top fed to layer 0), DGI / DGH [L, NT, 3H],
+// DCS [NT, ldcs], dh0 [L, B, H].  The weight gradients are single large GEMMs over these (host side).
+// Weights arrive TRANSPOSED so that every per-step data-gradient GEMM reads k-contiguous operands:
+//   w_ih_t[0] [W, 3H] (stack columns of W_ih0), w_ih_t[l >= 1] [H, 3H], w_hh_t[l] [H, 3H], wcs_t [H, ldcs].
+// The gate-math backward of layer l-1 runs in the epilogue of the GEMM that produces its dh
+// (dgi_l . W_ih[l] for l >= 1; the stack-head product for the top layer).
 int ppk_stackgru_seq_bwd(int64_t T, const int64_t* batch_sizes_host, int64_t B, int64_t NT,
-                         int64_t V, int64_t E, int64_t H, int64_t L, int64_t W, int64_t D,
+                         int64_t H, int64_t L, int64_t W, int64_t D,
                          const float* const* w_ih_t, const float* const* w_hh_t, const float* wcs_t,
                          const float* HP, const float* gates, const float* S, const float* CS, int64_t ldcs,
-                         const float* dHtop, float* dX, int64_t ldx, float* DGI, float* DGH, float* DCS,
+                         const float* dHtop, float* dXS, int64_t ks, float* DGI, float* DGH, float* DCS,
                          float* dh0, void* workspace, size_t ws_bytes, hipStream_t stream)
 {
-    SeqDims d{T, B, NT, E, H, L, W, D, V, ldx, ldcs};
+    SeqDims d{T, B, NT, H, L, W, D, 1, ks, ldcs};
     std::vector<int64_t> off;
     int rc = check_dims(d, batch_sizes_host, off);
     if (rc) return rc;
-    if (!w_ih_t || !w_hh_t || !wcs_t || !HP || !gates || !S || !CS || !dHtop || !dX || !DGI || !DGH || !DCS || !dh0 || !workspace)
+    if (!w_ih_t || !w_hh_t || !wcs_t || !HP || !gates || !S || !CS || !dHtop || !dXS || !DGI || !DGH || !DCS || !dh0 || !workspace)
         PPK_FAIL(PPK_ERR_NULL, "stackgru_seq_bwd: null pointer");
-    if (ws_bytes < ppk_stackgru_seq_bwd_workspace_bytes(B, H, W, D)) PPK_FAIL(PPK_ERR_WS, "stackgru_seq_bwd: workspace too small");
+    if (ws_bytes < ppk_stackgru_seq_bwd_workspace_bytes(B, W, D)) PPK_FAIL(PPK_ERR_WS, "stackgru_seq_bwd: workspace too small");
     char* cur = (char*)workspace;
     const size_t sbytes = sizeof(float) * (size_t)B * D * W;
     float* dSa = (float*)ppk_carve(cur, sbytes);
     float* dSb = (float*)ppk_carve(cur, sbytes);
-    float* dxup = (float*)ppk_carve(cur, sizeof(float) * (size_t)B * H);
     PPK_HIP(hipMemsetAsync(dSa, 0, sbytes, stream));
     PPK_HIP(hipMemsetAsync(dSb, 0, sbytes, stream));
     PPK_HIP(hipMemsetAsync(dh0, 0, sizeof(float) * (size_t)L * B * H, stream));
-    const int64_t I0 = E + W;
     const size_t lds_stack = sizeof(float) * (size_t)(D * W + 3 + W);
+    const int64_t H3 = 3 * H;
+
+    auto gru_bwd_problem = [&](const float* A, int64_t lda, int64_t a_rows, const float* Bm, int64_t ldb, int64_t K,
+                               int64_t l, int64_t Bt, int64_t o, const float* ext) {
+        ppk::NtProblem p{};
+        p.A = A; p.lda = lda; p.B = Bm; p.ldb = ldb;
+        p.M = (int)Bt; p.N = (int)H; p.K = (int)K; p.a_rows = (int)a_rows; p.H = (int)H;
+        p.epi = ppk::NT_GRU_BWD;
+        p.carry = dh0 + l * B * H; p.ext = ext;
+        p.gates_in = gates + (l * NT + o) * 4 * H; p.hp_in = HP + (l * NT + o) * H;
+        p.dgi = DGI + (l * NT + o) * H3; p.dgh = DGH + (l * NT + o) * H3;
+        return p;
+    };
 
     for (int64_t t = T - 1; t >= 0; --t) {
         const int64_t Bt = batch_sizes_host[t], o = off[(size_t)t], op = t > 0 ? off[(size_t)t - 1] : 0;
+        const int64_t Bn = t + 1 < T ? batch_sizes_host[t + 1] : 0, on = t + 1 < T ? off[(size_t)t + 1] : 0;
+        // top layer: dh = carry + dHtop_t + DCS_{t+1} . [W_c ; W_s]   (the stack of step t+1 read hidden[-1] of step t)
+        {
+            const ppk::NtProblem p = gru_bwd_problem(DCS + on * ldcs, ldcs, Bn, wcs_t, ldcs, ldcs, L - 1, Bt, o, dHtop + o * H);
+            rc = ppk::gemm_nt64(&p, 1, stream);
+            if (rc) return rc;
+        }
         for (int64_t l = L - 1; l >= 0; --l) {
-            float* carry = dh0 + l * B * H;
-            float* dgi = DGI + (l * NT + o) * 3 * H;
-            float* dgh = DGH + (l * NT + o) * 3 * H;
-            { ppk::ProfScope prof(ppk::PK_GATE_BWD, 4.0 * 14 * (double)Bt * H, stream);
-            k_gate_bwd<<<dim3(grid_for(Bt * H / 4)), dim3(256), 0, stream>>>(
-                carry, l == L - 1 ? dHtop + o * H : nullptr, l < L - 1 ? dxup : nullptr,
-                gates + (l * NT + o) * 4 * H, HP + (l * NT + o) * H, (int)Bt, (int)H, dgi, dgh); }
-            PPK_CHECK_LAUNCH("k_gate_bwd");
-            // carry += dgh . W_hh  and  dx = dgi . W_ih  (pre-transposed weights -> k-contiguous operands) in one launch
-            const ppk::GemmProblem pc{Bt, H, 3 * H, 1.f, dgh, 3 * H, w_hh_t[l], 3 * H, 1.f, carry, H, nullptr};
-            const ppk::GemmProblem px = l > 0
-                ? ppk::GemmProblem{Bt, H, 3 * H, 1.f, dgi, 3 * H, w_ih_t[l], 3 * H, 0.f, dxup, H, nullptr}
-                : ppk::GemmProblem{Bt, I0, 3 * H, 1.f, dgi, 3 * H, w_ih_t[0], 3 * H, 0.f, dX + o * ldx, ldx, nullptr};
-            rc = ppk::gemm_nt_pair(pc, px, stream);
+            const float* dgi = DGI + (l * NT + o) * H3;
+            const float* dgh = DGH + (l * NT + o) * H3;
+            ppk::NtProblem ps[2];
+            ps[0] = nt_store(dgh, H3, Bt, w_hh_t[l], H3, H, H3, dh0 + l * B * H, H, nullptr, 1.f, H);      // carry_l += dgh . W_hh
+            if (l > 0) ps[1] = gru_bwd_problem(dgi, H3, Bt, w_ih_t[l], H3, H3, l - 1, Bt, o, nullptr);     // dh_{l-1} = carry + dgi . W_ih
+            else       ps[1] = nt_store(dgi, H3, Bt, w_ih_t[0], H3, W, H3, dXS + o * ks, ks, nullptr, 0.f, H);
+            rc = ppk::gemm_nt64(ps, 2, stream);
             if (rc) return rc;
         }
         { ppk::ProfScope prof(ppk::PK_STACK_BWD, 12.0 * (double)Bt * D * W, stream);
         k_stack_bwd<<<dim3((unsigned)Bt), dim3(256), lds_stack, stream>>>(
-            dSa, dX + o * ldx + E, ldx, t == 0 ? nullptr : S + op * D * W, CS + o * ldcs, ldcs, DCS + o * ldcs, dSb, (int)D, (int)W); }
+            dSa, dXS + o * ks, ks, t == 0 ? nullptr : S + op * D * W, CS + o * ldcs, ldcs, DCS + o * ldcs, dSb, (int)D, (int)W); }
         PPK_CHECK_LAUNCH("k_stack_bwd");
         float* tmp = dSa; dSa = dSb; dSb = tmp;
-        rc = ppk::gemm(0, 1, Bt, H, 3 + W, 1.f, DCS + o * ldcs, ldcs, wcs_t, ldcs, 1.f, dh0 + (L - 1) * B * H, H, nullptr, nullptr, 0, stream);
-        if (rc) return rc;
     }
-    return PPK_OK;
+    // the stack of step 0 read the initial hidden state of the top layer
+    const ppk::NtProblem p = nt_store(DCS, ldcs, B, wcs_t, ldcs, H, ldcs, dh0 + (L - 1) * B * H, H, nullptr, 1.f, H);
+    return ppk::gemm_nt64(&p, 1, stream);
 }
 
 }  // extern "C"

@@ -4,7 +4,9 @@ Replaces `OPTIMIZER_FACTORY['adam'](params, lr=lr)` = `torch.optim.Adam`
 (reference reactions_vae.py:179-181, step at :96).  All parameters are views
 into ONE flat fp32 buffer and all gradients views into ONE flat gradient
 buffer, so the optimizer is a single launch and the data-parallel gradient
-all-reduce is a single RCCL collective over the flat gradient.
+all-reduce is a single RCCL collective over the flat gradient.  Every
+parameter starts on a 256-byte boundary of the flat buffer (the LDS-DMA GEMM
+kernels want 16-byte aligned operands); the gaps hold zeros and stay zero.
 """
 import torch
 
@@ -19,31 +21,31 @@ class FlatAdam:
             raise ValueError('optimizer got an empty parameter list')
         dev = self.params[0].device
         _C.require_gpu(*self.params)
-        n = sum(p.numel() for p in self.params)
-        self.flat = torch.empty(n, dtype=torch.float32, device=dev)
+        self.offsets = []
+        n = 0
+        for p in self.params:
+            self.offsets.append(n)
+            n += (p.numel() + 63) // 64 * 64
+        self.flat = torch.zeros(n, dtype=torch.float32, device=dev)
         self.flat_grad = torch.zeros(n, dtype=torch.float32, device=dev)
         self.exp_avg = torch.zeros(n, dtype=torch.float32, device=dev)
         self.exp_avg_sq = torch.zeros(n, dtype=torch.float32, device=dev)
-        off = 0
         with torch.no_grad():
-            for p in self.params:
+            for p, off in zip(self.params, self.offsets):
                 k = p.numel()
                 self.flat[off:off + k].copy_(p.detach().reshape(-1))
                 p.data = self.flat[off:off + k].view(p.shape)
                 p.grad = self.flat_grad[off:off + k].view(p.shape)
-                off += k
         self.param_groups = [dict(params=self.params, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)]
         self.step_count = 0
 
     def zero_grad(self, set_to_none: bool = False):
         # gradients stay views of the flat buffer so autograd accumulates in place
         self.flat_grad.zero_()
-        off = 0
-        for p in self.params:
+        for p, off in zip(self.params, self.offsets):
             k = p.numel()
             if p.grad is None or p.grad.data_ptr() != self.flat_grad.data_ptr() + 4 * off:
                 p.grad = self.flat_grad[off:off + k].view(p.shape)
-            off += k
 
     def step(self):
         g = self.param_groups[0]

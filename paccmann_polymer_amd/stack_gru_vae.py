@@ -172,9 +172,51 @@ def linear(x, weight, bias=None):
     return _Linear.apply(x, weight, bias)
 
 
+def _round_up(x, m):
+    return (x + m - 1) // m * m
+
+
+def _pad_units(t, H, Hp, dim, gates=1):
+    """Zero-pad `gates` consecutive blocks of H hidden units along `dim` to Hp units each."""
+    if Hp == H:
+        t = t.contiguous()
+        return t if t.data_ptr() % 16 == 0 else t.clone()      # kernels want 16-byte aligned operands
+    shape = list(t.shape)
+    shape[dim:dim + 1] = [gates, H]
+    t = t.reshape(shape)
+    pad_shape = list(shape)
+    pad_shape[dim + 1] = Hp - H
+    t = torch.cat([t, t.new_zeros(pad_shape)], dim=dim + 1)
+    shape[dim:dim + 2] = [gates * Hp]
+    return t.reshape(shape).contiguous()
+
+
+def _unpad_units(t, H, Hp, dim, gates=1):
+    if Hp == H:
+        return t
+    shape = list(t.shape)
+    shape[dim:dim + 1] = [gates, Hp]
+    t = t.reshape(shape).narrow(dim + 1, 0, H)
+    shape[dim:dim + 2] = [gates * H]
+    return t.reshape(shape).contiguous()
+
+
+def _gemm(ta, tb, M, N, K, A, lda, Bm, ldb, C, ldc, bias=None, ws=None, wsb=0):
+    _C.check(_lib.ppk_gemm_f32(ta, tb, M, N, K, 1.0, _C.p(A), lda, _C.p(Bm), ldb, 0.0, _C.p(C), ldc,
+                               _C.p(bias), _C.p(ws), wsb, _C.stream()))
+
+
 class _StackGRUSeq(torch.autograd.Function):
     """K1: the whole packed StackGRU sequence.  Returns the top layer's output of
-    every step, [NT, H] in packed order."""
+    every step, [NT, H] in packed order.
+
+    Host-side preparation per call (all on the GPU, outside the time loop):
+      * hidden units are zero-padded to a multiple of 32 (a padded unit has zero
+        weights and zero initial state, so it stays exactly 0 and receives zero gradient);
+      * the embedding half of the layer-0 input product becomes a [V, 3H] table,
+        table[v] = emb[v] . W_ih0[:, :E]^T + b_ih0, looked up per token inside the kernel;
+      * the backward takes transposed weight copies so its GEMMs read k-contiguous operands.
+    """
 
     @staticmethod
     def forward(ctx, tokens, batch_sizes, dims, h0, emb, wc, bc, wsi, bsi, *gru):
@@ -184,87 +226,94 @@ class _StackGRUSeq(torch.autograd.Function):
         T = batch_sizes.numel()
         B = int(batch_sizes[0])
         NT = int(tokens.numel())
-        I0 = E + W
-        ldx = (I0 + 3) // 4 * 4
-        ldcs = (3 + W + 3) // 4 * 4
+        Hp = _round_up(H, 32)
+        ks = _round_up(W, 32)
+        ldcs = _round_up(3 + W, 32)
+        f32 = dict(dtype=torch.float32, device=dev)
         w_ih = [gru[4 * l + 0] for l in range(L)]
         w_hh = [gru[4 * l + 1] for l in range(L)]
         b_ih = [gru[4 * l + 2] for l in range(L)]
         b_hh = [gru[4 * l + 3] for l in range(L)]
-        # stack heads as one [3+W, H] operand; layer-0 input weights padded to ldx columns
-        wcs = torch.cat([wc, wsi], dim=0).contiguous()
-        bcs = torch.cat([bc, bsi], dim=0).contiguous()
-        if ldx != I0:
-            w0 = torch.zeros(3 * H, ldx, dtype=torch.float32, device=dev)
-            w0[:, :I0] = w_ih[0]
-        else:
-            w0 = w_ih[0].contiguous()
-        w_ih_use = [w0] + [w.contiguous() for w in w_ih[1:]]
-        w_hh_use = [w.contiguous() for w in w_hh]
-        h0 = h0.contiguous()
 
-        f32 = dict(dtype=torch.float32, device=dev)
-        X = torch.empty(NT, ldx, **f32)
-        Hs = torch.empty(L, NT, H, **f32)
-        HP = torch.empty(L, NT, H, **f32)
-        gates = torch.empty(L, NT, 4 * H, **f32)
+        # [3+W, Hp] stack heads (controls rows 0..2, then the stack input layer)
+        wcs = _pad_units(torch.cat([wc, wsi], dim=0), H, Hp, 1)
+        bcs = torch.cat([bc, bsi], dim=0).contiguous()
+        w_hh_p = [_pad_units(_pad_units(w, H, Hp, 0, 3), H, Hp, 1) for w in w_hh]
+        b_hh_p = [_pad_units(b, H, Hp, 0, 3) for b in b_hh]
+        w_ih_p = [None] + [_pad_units(_pad_units(w, H, Hp, 0, 3), H, Hp, 1) for w in w_ih[1:]]
+        b_ih_p = [None] + [_pad_units(b, H, Hp, 0, 3) for b in b_ih[1:]]
+        w0 = _pad_units(w_ih[0], H, Hp, 0, 3)                       # [3Hp, E + W]
+        b0 = _pad_units(b_ih[0], H, Hp, 0, 3)
+        w0e = w0[:, :E]                                             # view, row stride E + W
+        wx0s = torch.zeros(3 * Hp, ks, **f32)
+        wx0s[:, :W] = w0[:, E:E + W]
+        embc = emb.contiguous()
+        table = torch.empty(V, 3 * Hp, **f32)
+        _gemm(0, 1, V, 3 * Hp, E, embc, E, w0e, E + W, table, 3 * Hp, bias=b0)
+        h0p = _pad_units(h0, H, Hp, 2)
+
+        XS = torch.empty(NT, ks, **f32)
+        Hs = torch.empty(L, NT, Hp, **f32)
+        HP = torch.empty(L, NT, Hp, **f32)
+        gates = torch.empty(L, NT, 4 * Hp, **f32)
         S = torch.empty(NT, D, W, **f32)
         CS = torch.empty(NT, ldcs, **f32)
-        wsb = _lib.ppk_stackgru_seq_fwd_workspace_bytes(B, H, W)
+        wsb = _lib.ppk_stackgru_seq_fwd_workspace_bytes(B, Hp, L, W)
         ws = _ws(wsb, dev)
         bs_host = batch_sizes.contiguous()
+        dummy = w_hh_p[0]
         _C.check(_lib.ppk_stackgru_seq_fwd(
-            T, ctypes.c_void_p(bs_host.data_ptr()), B, NT, V, E, H, L, W, D,
-            _C.p(tokens), _C.p(emb), _ptr_array(w_ih_use), ldx, _ptr_array(w_hh_use),
-            _ptr_array(b_ih), _ptr_array(b_hh), _C.p(wcs), _C.p(bcs), _C.p(h0),
-            _C.p(X), ldx, _C.p(Hs), _C.p(HP), _C.p(gates), _C.p(S), _C.p(CS), ldcs,
+            T, ctypes.c_void_p(bs_host.data_ptr()), B, NT, V, Hp, L, W, D,
+            _C.p(tokens), _C.p(table), _C.p(wx0s), ks,
+            _ptr_array([dummy] + w_ih_p[1:]), _ptr_array(w_hh_p),
+            _ptr_array([dummy] + b_ih_p[1:]), _ptr_array(b_hh_p), _C.p(wcs), _C.p(bcs), _C.p(h0p),
+            _C.p(XS), _C.p(Hs), _C.p(HP), _C.p(gates), _C.p(S), _C.p(CS), ldcs,
             _C.p(ws), wsb, _C.stream()))
         # transposed copies for the backward's data-gradient GEMMs (k-contiguous operands)
-        wcs_t = torch.zeros(H, ldcs, dtype=torch.float32, device=dev)
+        wcs_t = torch.zeros(Hp, ldcs, **f32)
         wcs_t[:, :3 + W] = wcs.t()
-        w_ih_t = [w_ih[0].t().contiguous()] + [w.t().contiguous() for w in w_ih[1:]]
-        w_hh_t = [w.t().contiguous() for w in w_hh]
-        ctx.save_for_backward(tokens, X, Hs, HP, gates, S, CS, wcs_t, *w_ih_t, *w_hh_t)
+        w_ih_t = [wx0s[:, :W].t().contiguous()] + [w.t().contiguous() for w in w_ih_p[1:]]
+        w_hh_t = [w.t().contiguous() for w in w_hh_p]
+        ctx.save_for_backward(tokens, XS, Hs, HP, gates, S, CS, wcs_t, embc, w0, *w_ih_t, *w_hh_t)
         ctx.bs_host = bs_host
-        ctx.dims = (V, E, H, L, W, D, T, B, NT, ldx, ldcs, I0)
+        ctx.dims = (V, E, H, Hp, L, W, D, T, B, NT, ks, ldcs)
         ctx.padding_idx = -1 if pad is None else int(pad)
-        return Hs[L - 1]
+        return _unpad_units(Hs[L - 1], H, Hp, 1)
 
     @staticmethod
     def backward(ctx, dHtop):
-        V, E, H, L, W, D, T, B, NT, ldx, ldcs, I0 = ctx.dims
+        V, E, H, Hp, L, W, D, T, B, NT, ks, ldcs = ctx.dims
         saved = ctx.saved_tensors
-        tokens, X, Hs, HP, gates, S, CS, wcs_t = saved[:8]
-        w_ih_t = list(saved[8:8 + L])
-        w_hh_t = list(saved[8 + L:8 + 2 * L])
-        dev = X.device
+        tokens, XS, Hs, HP, gates, S, CS, wcs_t, embc, w0 = saved[:10]
+        w_ih_t = list(saved[10:10 + L])
+        w_hh_t = list(saved[10 + L:10 + 2 * L])
+        dev = XS.device
         f32 = dict(dtype=torch.float32, device=dev)
-        dHtop = dHtop.contiguous()
-        dX = torch.empty(NT, ldx, **f32)
-        DGI = torch.empty(L, NT, 3 * H, **f32)
-        DGH = torch.empty(L, NT, 3 * H, **f32)
+        dHtop = _pad_units(dHtop, H, Hp, 1)
+        dXS = torch.empty(NT, ks, **f32)
+        DGI = torch.empty(L, NT, 3 * Hp, **f32)
+        DGH = torch.empty(L, NT, 3 * Hp, **f32)
         DCS = torch.empty(NT, ldcs, **f32)
-        dh0 = torch.empty(L, B, H, **f32)
-        wsb = _lib.ppk_stackgru_seq_bwd_workspace_bytes(B, H, W, D)
+        dh0 = torch.empty(L, B, Hp, **f32)
+        wsb = _lib.ppk_stackgru_seq_bwd_workspace_bytes(B, W, D)
         ws = _ws(wsb, dev)
         st = _C.stream()
         _C.check(_lib.ppk_stackgru_seq_bwd(
-            T, ctypes.c_void_p(ctx.bs_host.data_ptr()), B, NT, V, E, H, L, W, D,
+            T, ctypes.c_void_p(ctx.bs_host.data_ptr()), B, NT, Hp, L, W, D,
             _ptr_array(w_ih_t), _ptr_array(w_hh_t), _C.p(wcs_t),
             _C.p(HP), _C.p(gates), _C.p(S), _C.p(CS), ldcs,
-            _C.p(dHtop), _C.p(dX), ldx, _C.p(DGI), _C.p(DGH), _C.p(DCS), _C.p(dh0),
+            _C.p(dHtop), _C.p(dXS), ks, _C.p(DGI), _C.p(DGH), _C.p(DCS), _C.p(dh0),
             _C.p(ws), wsb, st))
 
         # ---- weight gradients: single large TN GEMMs over the saved activations
-        gws_b = _lib.ppk_gemm_f32_workspace_bytes(3 * H, max(H, I0), NT)
+        gws_b = _lib.ppk_gemm_f32_workspace_bytes(3 * Hp, max(Hp, ks), NT)
         gws = _ws(gws_b, dev)
-        cws_b = _lib.ppk_colsum_workspace_bytes(NT, 3 * H)
+        cws_b = _lib.ppk_colsum_workspace_bytes(NT, 3 * Hp)
         cws = _ws(cws_b, dev)
 
-        def tn(A, lda, M, Bm, ldb, N):
+        def tn(A, lda, M, Bm, ldb, N, K=NT):
             out = torch.empty(M, N, **f32)
-            _C.check(_lib.ppk_gemm_f32(1, 0, M, N, NT, 1.0, _C.p(A), lda, _C.p(Bm), ldb, 0.0,
-                                       _C.p(out), N, None, _C.p(gws), gws_b, st))
+            _gemm(1, 0, M, N, K, A, lda, Bm, ldb, out, N, ws=gws, wsb=gws_b)
             return out
 
         def colsum(A, lda, C):
@@ -272,22 +321,35 @@ class _StackGRUSeq(torch.autograd.Function):
             _C.check(_lib.ppk_colsum(_C.p(A), lda, NT, C, 0.0, _C.p(out), _C.p(cws), cws_b, st))
             return out
 
-        gru_grads = []
-        for l in range(L):
-            inp, ldin, Il = (X, ldx, I0) if l == 0 else (Hs[l - 1], H, H)
-            gru_grads += [
-                tn(DGI[l], 3 * H, 3 * H, inp, ldin, Il),
-                tn(DGH[l], 3 * H, 3 * H, HP[l], H, H),
-                colsum(DGI[l], 3 * H, 3 * H),
-                colsum(DGH[l], 3 * H, 3 * H),
-            ]
-        dwcs = tn(DCS, ldcs, 3 + W, HP[L - 1], H, H)
-        dbcs = colsum(DCS, ldcs, 3 + W)
+        def w_grad(g):          # [3Hp, Hp] -> [3H, H]
+            return _unpad_units(_unpad_units(g, H, Hp, 0, 3), H, Hp, 1)
+
+        # layer 0: stack columns from XS; embedding columns through the per-token table
+        onehot = torch.zeros(NT, V, **f32)
+        onehot.scatter_(1, tokens.view(-1, 1), 1.0)
+        dtable = tn(onehot, V, V, DGI[0], 3 * Hp, 3 * Hp)                     # [V, 3Hp] rows of DGI0 summed per token
+        dw0s = tn(DGI[0], 3 * Hp, 3 * Hp, XS, ks, W)                          # [3Hp, W]
+        dw0e = tn(dtable, 3 * Hp, 3 * Hp, embc, E, E, K=V)                    # [3Hp, E] = dtable^T . emb
         demb = torch.empty(V, E, **f32)
-        eb = _lib.ppk_embedding_bwd_workspace_bytes(NT, V, E)
-        ews = _ws(eb, dev)
-        _C.check(_lib.ppk_embedding_bwd(_C.p(dX), ldx, _C.p(tokens), NT, V, E, ctx.padding_idx,
-                                        _C.p(demb), _C.p(ews), eb, st))
+        _gemm(0, 0, V, E, 3 * Hp, dtable, 3 * Hp, w0, E + W, demb, E)         # dtable . W_ih0[:, :E]
+        if ctx.padding_idx >= 0:
+            demb[ctx.padding_idx].zero_()
+        gru_grads = [
+            _unpad_units(torch.cat([dw0e, dw0s], dim=1), H, Hp, 0, 3),
+            w_grad(tn(DGH[0], 3 * Hp, 3 * Hp, HP[0], Hp, Hp)),
+            _unpad_units(colsum(DGI[0], 3 * Hp, 3 * Hp), H, Hp, 0, 3),
+            _unpad_units(colsum(DGH[0], 3 * Hp, 3 * Hp), H, Hp, 0, 3),
+        ]
+        for l in range(1, L):
+            gru_grads += [
+                w_grad(tn(DGI[l], 3 * Hp, 3 * Hp, Hs[l - 1], Hp, Hp)),
+                w_grad(tn(DGH[l], 3 * Hp, 3 * Hp, HP[l], Hp, Hp)),
+                _unpad_units(colsum(DGI[l], 3 * Hp, 3 * Hp), H, Hp, 0, 3),
+                _unpad_units(colsum(DGH[l], 3 * Hp, 3 * Hp), H, Hp, 0, 3),
+            ]
+        dwcs = _unpad_units(tn(DCS, ldcs, 3 + W, HP[L - 1], Hp, Hp), H, Hp, 1)
+        dbcs = colsum(DCS, ldcs, 3 + W)
+        dh0 = _unpad_units(dh0, H, Hp, 2)
         return (None, None, None, dh0, demb, dwcs[:3], dbcs[:3], dwcs[3:], dbcs[3:], *gru_grads)
 
 

@@ -32,7 +32,10 @@ __global__ __launch_bounds__(256) void k_rows(const float* __restrict__ src, lon
 }
 
 // ---- column sums: out[c] = sum_r A[r, c] ; two passes, fixed order ----------
-constexpr int CS_CHUNK = 512;   // rows per partial
+// pass 1: a block sums CS_CHUNK rows of 256 columns, 8 independent row streams per thread
+// (HBM-bound read of A); pass 2: 64 columns per block, 4 slices of the partials per column
+// summed in double and combined in a fixed order.
+constexpr int CS_CHUNK = 128;   // rows per partial
 __global__ __launch_bounds__(256) void k_colsum_part(const float* __restrict__ A, long long lda, long long R, int C,
                                                      float* __restrict__ part)
 {
@@ -40,18 +43,31 @@ __global__ __launch_bounds__(256) void k_colsum_part(const float* __restrict__ A
     const long long r1 = r0 + CS_CHUNK < R ? r0 + CS_CHUNK : R;
     const int c = blockIdx.x * 256 + threadIdx.x;
     if (c >= C) return;
-    float acc = 0.f;
-    for (long long r = r0; r < r1; ++r) acc += A[r * lda + c];
-    part[(long long)blockIdx.y * C + c] = acc;
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    long long r = r0;
+    for (; r + 8 <= r1; r += 8)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc[k] += A[(r + k) * lda + c];
+    for (; r < r1; ++r) acc[0] += A[r * lda + c];
+    part[(long long)blockIdx.y * C + c] = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
 }
 __global__ __launch_bounds__(256) void k_colsum_final(const float* __restrict__ part, int nparts, int C, float beta,
                                                       float* __restrict__ out)
 {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= C) return;
+    __shared__ double red[4][64];
+    const int cl = threadIdx.x & 63, sl = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl;
+    const int per = (nparts + 3) / 4;
+    const int p0 = sl * per, p1 = p0 + per < nparts ? p0 + per : nparts;
     double acc = 0.0;
-    for (int p = 0; p < nparts; ++p) acc += (double)part[(long long)p * C + c];
-    out[c] = (beta != 0.f ? beta * out[c] : 0.f) + (float)acc;
+    if (c < C)
+        for (int p = p0; p < p1; ++p) acc += (double)part[(long long)p * C + c];
+    red[sl][cl] = acc;
+    __syncthreads();
+    if (sl == 0 && c < C) {
+        const double t = (red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl]);
+        out[c] = (beta != 0.f ? beta * out[c] : 0.f) + (float)t;
+    }
 }
 
 // ---- embedding gradient: dEmb[v, :] = sum_{rows with tok == v} dX[row, 0:E] ----
@@ -315,7 +331,7 @@ int ppk_colsum(const float* A, int64_t lda, int64_t rows, int64_t cols, float be
     dim3 grid((unsigned)((cols + 255) / 256), (unsigned)nparts);
     k_colsum_part<<<grid, dim3(256), 0, stream>>>(A, lda, rows, (int)cols, (float*)workspace);
     PPK_CHECK_LAUNCH("k_colsum_part");
-    k_colsum_final<<<dim3(grid.x), dim3(256), 0, stream>>>((const float*)workspace, nparts, (int)cols, beta, out);
+    k_colsum_final<<<dim3((unsigned)((cols + 63) / 64)), dim3(256), 0, stream>>>((const float*)workspace, nparts, (int)cols, beta, out);
     PPK_CHECK_LAUNCH("k_colsum_final");
     return PPK_OK;
 }

@@ -126,6 +126,13 @@ int ppk_gemm_f32(int transA, int transB, int64_t M, int64_t N, int64_t K, float 
                  float* C, int64_t ldc, const float* bias, void* workspace, size_t ws_bytes,
                  ppk_stream_t stream);
 
+/* Tuning / test hook of the NT GEMM family behind ppk_gemm_f32 (NT, K % 32 == 0) and K1: launches
+ * whose big-tile grid has at most `limit` tiles run on the small-tile kernels (one 32-row tile per
+ * workgroup, K split over its four waves) that keep short packed-batch tail steps — and the
+ * reference's own <= 21-sequence bundles (reactions_vae.py:52-59) — off the single-CU latency floor.
+ * limit < 0 only queries; returns the value in force (default 128 = half the CUs). */
+int64_t ppk_nt_small_grid_limit(int64_t limit);
+
 /* ---- K1: stack-augmented GRU sequence (packed, length-sorted batch) -------
  * Replaces the per-timestep loop of paccmann_chemistry StackGRU / nn.GRU that
  * the reference drives from paccmann_polymer/models/paccmann_encoder.py:166

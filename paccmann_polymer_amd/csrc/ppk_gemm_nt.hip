@@ -22,6 +22,7 @@
 // fewer LDS bytes per MFMA (3 accumulators per A fragment) is what pays.
 #include "ppk_common.h"
 #include "ppk_kernels.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -33,11 +34,12 @@ constexpr int BK = 32;
 
 template <int N> __device__ __forceinline__ void wait_vmcnt()
 {
-    static_assert(N == 0 || N == 4 || N == 7 || N == 8, "add the count");
+    static_assert(N == 0 || N == 4 || N == 7 || N == 8 || N == 16, "add the count");
     if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     else if constexpr (N == 7) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
 }
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
@@ -62,8 +64,23 @@ __device__ __forceinline__ void tile_to_lds(float* t, const f32x16& acc, int li,
 __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 __device__ __forceinline__ void st4(float* p, const f32x4& v) { *reinterpret_cast<f32x4*>(p) = v; }
 
-// C = acc + bias + beta C on a transposed tile; col0 = first of the tile's 32 columns
-__device__ __forceinline__ void epi_store(const ppk::NtProblem& g, const float* t, int row0, int col0, long long coff, int ncols_total, int lane)
+// sum of NPART partial tiles (fixed order) at element offset o
+template <int NPART>
+__device__ __forceinline__ f32x4 ldsum(const float* t, int pstride, int o)
+{
+    f32x4 v = ld4(t + o);
+#pragma unroll
+    for (int k = 1; k < NPART; ++k) v += ld4(t + k * pstride + o);
+    return v;
+}
+
+// Every epilogue handles passes p0 .. p0 + NP - 1 of a transposed 32 x 32 tile that is the sum of
+// NPART partial tiles (K split over waves), `pstride` floats apart.
+
+// C = acc + bias + beta C ; col0 = first of the tile's 32 columns, coff = column offset of the tile group in C / bias
+template <int NP, int NPART>
+__device__ __forceinline__ void epi_store(const ppk::NtProblem& g, const float* t, int pstride, int p0, int row0, int col0,
+                                          long long coff, int ncols_total, int lane)
 {
     const int c4 = (lane & 7) * 4, col = col0 + c4;
     const bool vec = !(g.ldc & 3) && !((uintptr_t)g.C & 15) && !(coff & 3) && col + 3 < ncols_total;
@@ -72,10 +89,10 @@ __device__ __forceinline__ void epi_store(const ppk::NtProblem& g, const float* 
 #pragma unroll
         for (int k = 0; k < 4; ++k) if (col + k < ncols_total) bv[k] = g.bias[coff + col + k];
 #pragma unroll
-    for (int p = 0; p < 4; ++p) {
-        const int rl = 8 * p + (lane >> 3), row = row0 + rl;
+    for (int pp = 0; pp < NP; ++pp) {
+        const int rl = 8 * (p0 + pp) + (lane >> 3), row = row0 + rl;
         if (row >= g.M) continue;
-        f32x4 v = ld4(t + rl * EPI_LD + c4);
+        f32x4 v = ldsum<NPART>(t, pstride, rl * EPI_LD + c4);
         if (row >= g.a_rows) v = f32x4{0.f, 0.f, 0.f, 0.f};
         float* cp = g.C + (long long)row * g.ldc + coff + col;
         if (vec) {
@@ -95,16 +112,17 @@ __device__ __forceinline__ void epi_store(const ppk::NtProblem& g, const float* 
 }
 
 // backward of the GRU gate math: dh = acc + carry + ext ; H % 4 == 0
-__device__ __forceinline__ void epi_gru_bwd(const ppk::NtProblem& g, const float* t, int row0, int col0, int lane)
+template <int NP, int NPART>
+__device__ __forceinline__ void epi_gru_bwd(const ppk::NtProblem& g, const float* t, int pstride, int p0, int row0, int col0, int lane)
 {
     const int H = g.H, c4 = (lane & 7) * 4, col = col0 + c4;
     if (col >= H) return;
     const int mlast = g.M - 1;
-    f32x4 cr[4], ex[4], gr[4], gz[4], gn[4], gh[4], hp[4];
-    // issue every load of the four passes before the first use (rows clamped, stores guarded)
+    f32x4 cr[NP], ex[NP], gr[NP], gz[NP], gn[NP], gh[NP], hp[NP];
+    // issue every load of all passes before the first use (rows clamped, stores guarded)
 #pragma unroll
-    for (int p = 0; p < 4; ++p) {
-        int row = row0 + 8 * p + (lane >> 3); row = row < mlast ? row : mlast;
+    for (int p = 0; p < NP; ++p) {
+        int row = row0 + 8 * (p0 + p) + (lane >> 3); row = row < mlast ? row : mlast;
         const long long rh = (long long)row * H + col;
         cr[p] = ld4(g.carry + rh);
         ex[p] = g.ext ? ld4(g.ext + rh) : f32x4{0.f, 0.f, 0.f, 0.f};
@@ -113,10 +131,10 @@ __device__ __forceinline__ void epi_gru_bwd(const ppk::NtProblem& g, const float
         hp[p] = ld4(g.hp_in + rh);
     }
 #pragma unroll
-    for (int p = 0; p < 4; ++p) {
-        const int rl = 8 * p + (lane >> 3), row = row0 + rl;
+    for (int p = 0; p < NP; ++p) {
+        const int rl = 8 * (p0 + p) + (lane >> 3), row = row0 + rl;
         if (row >= g.M) continue;
-        f32x4 a = ld4(t + rl * EPI_LD + c4);
+        f32x4 a = ldsum<NPART>(t, pstride, rl * EPI_LD + c4);
         if (row >= g.a_rows) a = f32x4{0.f, 0.f, 0.f, 0.f};
         f32x4 dr, dz, dn, dnr, c;
 #pragma unroll
@@ -138,17 +156,18 @@ __device__ __forceinline__ void epi_gru_bwd(const ppk::NtProblem& g, const float
 }
 
 // GRU cell on transposed r / z / n tiles (t, t + EPI_TILE, t + 2 EPI_TILE); u0 = first hidden unit of the tile; H % 4 == 0
-__device__ __forceinline__ void epi_gru_fwd(const ppk::NtProblem& g, const float* t, int row0, int u0, int lane)
+template <int NP, int NPART>
+__device__ __forceinline__ void epi_gru_fwd(const ppk::NtProblem& g, const float* t, int pstride, int p0, int row0, int u0, int lane)
 {
     const int H = g.H, c4 = (lane & 7) * 4, u = u0 + c4;
     if (u >= H) return;
     const int mlast = g.M - 1;
     f32x4 b0 = {0.f, 0.f, 0.f, 0.f}, b1 = b0, b2 = b0;
     if (g.bias) { b0 = ld4(g.bias + u); b1 = ld4(g.bias + H + u); b2 = ld4(g.bias + 2 * H + u); }
-    f32x4 hr[4], hz[4], hn[4], hp[4], tr[4], tz[4], tn[4];
+    f32x4 hr[NP], hz[NP], hn[NP], hp[NP], tr[NP], tz[NP], tn[NP];
 #pragma unroll
-    for (int p = 0; p < 4; ++p) {
-        int row = row0 + 8 * p + (lane >> 3); row = row < mlast ? row : mlast;
+    for (int p = 0; p < NP; ++p) {
+        int row = row0 + 8 * (p0 + p) + (lane >> 3); row = row < mlast ? row : mlast;
         const float* ghr = g.gh + (long long)row * 3 * H + u;
         hr[p] = ld4(ghr); hz[p] = ld4(ghr + H); hn[p] = ld4(ghr + 2 * H);
         hp[p] = ld4(g.hprev + (long long)row * H + u);
@@ -160,10 +179,11 @@ __device__ __forceinline__ void epi_gru_fwd(const ppk::NtProblem& g, const float
         }
     }
 #pragma unroll
-    for (int p = 0; p < 4; ++p) {
-        const int rl = 8 * p + (lane >> 3), row = row0 + rl;
+    for (int p = 0; p < NP; ++p) {
+        const int rl = 8 * (p0 + p) + (lane >> 3), row = row0 + rl;
         if (row >= g.M) continue;
-        const f32x4 ar = ld4(t + rl * EPI_LD + c4), az = ld4(t + EPI_TILE + rl * EPI_LD + c4), an = ld4(t + 2 * EPI_TILE + rl * EPI_LD + c4);
+        const int o = rl * EPI_LD + c4;
+        const f32x4 ar = ldsum<NPART>(t, pstride, o), az = ldsum<NPART>(t + EPI_TILE, pstride, o), an = ldsum<NPART>(t + 2 * EPI_TILE, pstride, o);
         f32x4 rr, zz, nn, hh;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -254,8 +274,8 @@ __global__ __launch_bounds__(256) void k_nt64(const NtBatch nb)
     float* t = lds + wave * EPI_TILE;
     tile_to_lds(t, acc, li, h);
     const int row0 = m0 + wm * 32, col0 = n0 + wn * 32;
-    if (g.epi == ppk::NT_GRU_BWD) epi_gru_bwd(g, t, row0, col0, lane);
-    else epi_store(g, t, row0, col0, 0, g.N, lane);
+    if (g.epi == ppk::NT_GRU_BWD) epi_gru_bwd<4, 1>(g, t, 0, 0, row0, col0, lane);
+    else epi_store<4, 1>(g, t, 0, 0, row0, col0, 0, g.N, lane);
 }
 
 // ---------------------------------------------------------------------------
@@ -342,15 +362,191 @@ __global__ __launch_bounds__(256) void k_ntF(const NtBatch nb)
     for (int q = 0; q < 3; ++q) tile_to_lds(t + q * EPI_TILE, acc[q], li, h);
     const int row0 = m0 + wave * 32;
     if (g.epi == ppk::NT_GRU_FWD) {
-        epi_gru_fwd(g, t, row0, j0, lane);
+        epi_gru_fwd<4, 1>(g, t, 0, 0, row0, j0, lane);
     } else {
         // plain store in gate layout: C[row, q * H + unit]
 #pragma unroll
-        for (int q = 0; q < 3; ++q) epi_store(g, t + q * EPI_TILE, row0, j0, (long long)q * H, H, lane);
+        for (int q = 0; q < 3; ++q) epi_store<4, 1>(g, t + q * EPI_TILE, 0, 0, row0, j0, (long long)q * H, H, lane);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Small-grid variants for the short tail steps of a packed batch (and for the reference's own
+// bundles of <= 21 sequences): one 32-row output tile per workgroup and K SPLIT OVER THE FOUR
+// WAVES (wave w takes K tiles w, w + 4, ...).  Each wave stages and reads only its own LDS
+// region, so the main loop has no barrier at all; the four partial tiles are added in wave
+// order in the epilogue.  A 64 x 64 x 1536 tile keeps one CU's matrix pipes busy for >= 20 us
+// whatever the grid; this shape spreads the same work over 4x (k_nt32) / 4x (k_ntFs) more CUs.
+// ---------------------------------------------------------------------------
+template <int BROWS>      // B rows per tile: 32 (k_nt32) or 96 (k_ntFs)
+struct SmallTile {
+    static constexpr int PA = 4, PB = BROWS / 8;            // 8-row LDS-DMA pieces per K tile
+    static constexpr int BUF = (32 + BROWS) * BK;           // floats per buffer
+    static constexpr int WAVE_LDS = 2 * BUF;                // two buffers per wave
+};
+
+__global__ __launch_bounds__(256) void k_nt32(const NtBatch nb)
+{
+    using ST = SmallTile<32>;
+    __shared__ __align__(1024) float lds[4 * ST::WAVE_LDS];
+
+    const ppk::NtProblem& g = nb.p[blockIdx.z];
+    const int m0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
+    if (m0 >= g.M || n0 >= g.N) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, h = lane >> 5;
+    float* wl = lds + wave * ST::WAVE_LDS;
+
+    const int r8 = lane >> 3, pc = lane & 7;
+    const float* ga[4];
+    const float* gb[4];
+    const int arows = g.a_rows < g.M ? g.a_rows : g.M;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const int row = p * 8 + r8;
+        const int lc = pc ^ ((row >> 1) & 7);
+        int gr = m0 + row; gr = gr < arows ? gr : arows - 1; gr = gr < 0 ? 0 : gr;
+        ga[p] = g.A + (long long)gr * g.lda + lc * 4 + wave * BK;
+        int gc = n0 + row; gc = gc < g.N ? gc : g.N - 1;
+        gb[p] = g.B + (long long)gc * g.ldb + lc * 4 + wave * BK;
+    }
+    auto stage = [&](int buf) {
+        float* la = wl + buf * ST::BUF;
+        float* lb = la + 32 * BK;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) { __builtin_amdgcn_global_load_lds(ga[p], PPK_LDS_PTR(la + p * 256), 16, 0, 0); ga[p] += 4 * BK; }
+#pragma unroll
+        for (int p = 0; p < 4; ++p) { __builtin_amdgcn_global_load_lds(gb[p], PPK_LDS_PTR(lb + p * 256), 16, 0, 0); gb[p] += 4 * BK; }
+    };
+    const int sw = (li >> 1) & 7;
+    int xo[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) xo[c] = 4 * ((2 * c + h) ^ sw);
+    const int arow = li * BK, brow = 32 * BK + li * BK;
+
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+
+    const int nk = arows > 0 ? g.K / BK : 0;
+    const int nkw = (nk - wave + 3) >> 2;           // K tiles of this wave
+    if (nkw > 0) stage(0);
+    if (nkw > 1) stage(1);
+    for (int i = 0; i < nkw; ++i) {
+        if (i + 1 < nkw) wait_vmcnt<8>(); else wait_vmcnt<0>();
+        const float* base = wl + (i & 1) * ST::BUF;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const f32x4 a = *(const f32x4*)(base + arow + xo[c]);
+            const f32x4 b = *(const f32x4*)(base + brow + xo[c]);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], b[s], acc, 0, 0, 0);
+        }
+        // this wave's reads of the buffer have returned (the MFMAs consumed them): refill it
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (i + 2 < nkw) stage(i & 1);
+    }
+    __syncthreads();
+    tile_to_lds(lds + wave * EPI_TILE, acc, li, h);
+    __syncthreads();
+    if (g.epi == ppk::NT_GRU_BWD) epi_gru_bwd<1, 4>(g, lds, EPI_TILE, wave, m0, n0, lane);
+    else epi_store<1, 4>(g, lds, EPI_TILE, wave, m0, n0, 0, g.N, lane);
+}
+
+__global__ __launch_bounds__(256) void k_ntFs(const NtBatch nb)
+{
+    using ST = SmallTile<96>;
+    __shared__ __align__(1024) float lds[4 * ST::WAVE_LDS];
+
+    const ppk::NtProblem& g = nb.p[blockIdx.z];
+    const int H = g.H;
+    const int m0 = blockIdx.y * 32, j0 = blockIdx.x * 32;
+    if (m0 >= g.M || j0 >= H) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, h = lane >> 5;
+    float* wl = lds + wave * ST::WAVE_LDS;
+
+    const int r8 = lane >> 3, pc = lane & 7;
+    const float* ga[4];
+    const float* gb[12];
+    const int arows = g.a_rows < g.M ? g.a_rows : g.M;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const int row = p * 8 + r8;
+        const int lc = pc ^ ((row >> 1) & 7);
+        int gr = m0 + row; gr = gr < arows ? gr : arows - 1; gr = gr < 0 ? 0 : gr;
+        ga[p] = g.A + (long long)gr * g.lda + lc * 4 + wave * BK;
+    }
+#pragma unroll
+    for (int p = 0; p < 12; ++p) {
+        const int row = p * 8 + r8;                       // 0..95: gate = row / 32, unit = row % 32
+        const int lc = pc ^ ((row >> 1) & 7);
+        int u = j0 + (row & 31); u = u < H ? u : H - 1;
+        gb[p] = g.B + ((long long)(row >> 5) * H + u) * g.ldb + lc * 4 + wave * BK;
+    }
+    auto stage = [&](int buf) {
+        float* la = wl + buf * ST::BUF;
+        float* lb = la + 32 * BK;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) { __builtin_amdgcn_global_load_lds(ga[p], PPK_LDS_PTR(la + p * 256), 16, 0, 0); ga[p] += 4 * BK; }
+#pragma unroll
+        for (int p = 0; p < 12; ++p) { __builtin_amdgcn_global_load_lds(gb[p], PPK_LDS_PTR(lb + p * 256), 16, 0, 0); gb[p] += 4 * BK; }
+    };
+    const int sw = (li >> 1) & 7;
+    int xo[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) xo[c] = 4 * ((2 * c + h) ^ sw);
+    const int arow = li * BK, brow = 32 * BK + li * BK;
+
+    f32x16 acc[3];
+#pragma unroll
+    for (int q = 0; q < 3; ++q)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
+
+    const int nk = arows > 0 ? g.K / BK : 0;
+    const int nkw = (nk - wave + 3) >> 2;
+    if (nkw > 0) stage(0);
+    if (nkw > 1) stage(1);
+    for (int i = 0; i < nkw; ++i) {
+        if (i + 1 < nkw) wait_vmcnt<16>(); else wait_vmcnt<0>();
+        const float* base = wl + (i & 1) * ST::BUF;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const f32x4 a = *(const f32x4*)(base + arow + xo[c]);
+            f32x4 b[3];
+#pragma unroll
+            for (int q = 0; q < 3; ++q) b[q] = *(const f32x4*)(base + brow + q * 32 * BK + xo[c]);
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int q = 0; q < 3; ++q) acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], b[q][s], acc[q], 0, 0, 0);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (i + 2 < nkw) stage(i & 1);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 3; ++q) tile_to_lds(lds + (wave * 3 + q) * EPI_TILE, acc[q], li, h);
+    __syncthreads();
+    if (g.epi == ppk::NT_GRU_FWD) {
+        epi_gru_fwd<1, 4>(g, lds, 3 * EPI_TILE, wave, m0, j0, lane);
+    } else {
+#pragma unroll
+        for (int q = 0; q < 3; ++q) epi_store<1, 4>(g, lds + q * EPI_TILE, 3 * EPI_TILE, wave, m0, j0, (long long)q * H, H, lane);
     }
 }
 
 inline long long cdiv(long long a, long long b) { return (a + b - 1) / b; }
+
+// big-tile launches with at most this many tiles go to the small-tile kernels
+// (env PPK_NT_SMALL or ppk_nt_small_grid_limit(); measured best at half the CU count)
+long long g_small_limit = -1;
+long long small_grid_limit()
+{
+    if (g_small_limit < 0) { const char* e = getenv("PPK_NT_SMALL"); g_small_limit = e ? atoll(e) : 128; }
+    return g_small_limit;
+}
 
 int check_common(const ppk::NtProblem& p, const char* who)
 {
@@ -377,7 +573,7 @@ int gemm_nt64(const NtProblem* ps, int count, hipStream_t stream)
 {
     if (count < 1 || count > NT_MAX_GROUP) PPK_FAIL(PPK_ERR_UNSUP, "gemm_nt64: 1..%d problems", NT_MAX_GROUP);
     NtBatch nb;
-    long long gx = 0, gy = 0;
+    long long gx = 0, gy = 0, gx32 = 0, gy32 = 0, tiles64 = 0, tilesF = 0;
     double flops = 0;
     for (int i = 0; i < count; ++i) {
         const NtProblem& p = ps[i];
@@ -395,9 +591,20 @@ int gemm_nt64(const NtProblem* ps, int count, hipStream_t stream)
         nb.p[i] = p;
         gx = gx > cdiv(p.N, 64) ? gx : cdiv(p.N, 64);
         gy = gy > cdiv(p.M, 64) ? gy : cdiv(p.M, 64);
+        gx32 = gx32 > cdiv(p.N, 32) ? gx32 : cdiv(p.N, 32);
+        gy32 = gy32 > cdiv(p.M, 32) ? gy32 : cdiv(p.M, 32);
+        tiles64 += cdiv(p.N, 64) * cdiv(p.M, 64);
         flops += 2.0 * (double)p.M * (double)p.N * (double)p.K;
     }
+    (void)tilesF;
     if (gx == 0 || gy == 0) return PPK_OK;
+    if (tiles64 <= small_grid_limit()) {
+        // fewer tiles than half the CUs: 32 x 32 tiles with K split over the waves
+        ProfScope prof(PK_GEMM_NT32, flops, stream);
+        k_nt32<<<dim3((unsigned)gx32, (unsigned)gy32, (unsigned)count), dim3(256), 0, stream>>>(nb);
+        PPK_CHECK_LAUNCH("k_nt32");
+        return PPK_OK;
+    }
     ProfScope prof(PK_GEMM_NT64, flops, stream);
     k_nt64<<<dim3((unsigned)gx, (unsigned)gy, (unsigned)count), dim3(256), 0, stream>>>(nb);
     PPK_CHECK_LAUNCH("k_nt64");
@@ -408,7 +615,7 @@ int gemm_ntF(const NtProblem* ps, int count, hipStream_t stream)
 {
     if (count < 1 || count > NT_MAX_GROUP) PPK_FAIL(PPK_ERR_UNSUP, "gemm_ntF: 1..%d problems", NT_MAX_GROUP);
     NtBatch nb;
-    long long gx = 0, gy = 0;
+    long long gx = 0, gy = 0, gx32 = 0, gy32 = 0, tiles64 = 0, tilesF = 0;
     double flops = 0;
     for (int i = 0; i < count; ++i) {
         const NtProblem& p = ps[i];
@@ -428,9 +635,18 @@ int gemm_ntF(const NtProblem* ps, int count, hipStream_t stream)
         nb.p[i] = p;
         gx = gx > cdiv(p.H, 32) ? gx : cdiv(p.H, 32);
         gy = gy > cdiv(p.M, 128) ? gy : cdiv(p.M, 128);
+        gy32 = gy32 > cdiv(p.M, 32) ? gy32 : cdiv(p.M, 32);
+        tilesF += cdiv(p.H, 32) * cdiv(p.M, 128);
         flops += 2.0 * (double)p.M * (double)p.N * (double)p.K;
     }
+    (void)gx32; (void)tiles64;
     if (gx == 0 || gy == 0) return PPK_OK;
+    if (tilesF <= small_grid_limit()) {
+        ProfScope prof(PK_GEMM_NTFS, flops, stream);
+        k_ntFs<<<dim3((unsigned)gx, (unsigned)gy32, (unsigned)count), dim3(256), 0, stream>>>(nb);
+        PPK_CHECK_LAUNCH("k_ntFs");
+        return PPK_OK;
+    }
     ProfScope prof(PK_GEMM_NTF, flops, stream);
     k_ntF<<<dim3((unsigned)gx, (unsigned)gy, (unsigned)count), dim3(256), 0, stream>>>(nb);
     PPK_CHECK_LAUNCH("k_ntF");
@@ -438,3 +654,15 @@ int gemm_ntF(const NtProblem* ps, int count, hipStream_t stream)
 }
 
 }  // namespace ppk
+
+extern "C" {
+
+// Tuning / test hook: NT GEMM launches whose big-tile grid has at most `limit` tiles use the
+// small-tile kernels (K split over the waves).  limit < 0 only queries.  Returns the value in force.
+int64_t ppk_nt_small_grid_limit(int64_t limit)
+{
+    if (limit >= 0) g_small_limit = limit;
+    return small_grid_limit();
+}
+
+}  // extern "C"

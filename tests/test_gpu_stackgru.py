@@ -56,6 +56,25 @@ def build_pair(params, seed, dtype):
     (SMALL, 5, 3, 9, 0), (SMALL, 1, 4, 4, 1), (ODD, 7, 3, 12, 2), (SMALL, 9, 5, 5, 3), (FULL, 16, 5, 30, 4),
 ])
 def test_train_step_matches_oracle_fp64(params, B, lo, hi, seed):
+    check_train_step(params, B, lo, hi, seed)
+
+
+@pytest.mark.parametrize('limit', [0, 1 << 30])
+@pytest.mark.parametrize('params,B,lo,hi,seed', [(ODD, 150, 3, 12, 5), (SMALL, 70, 2, 7, 6)])
+def test_train_step_both_tile_families(params, B, lo, hi, seed, limit):
+    """The NT GEMM kernels come in a big-tile family (k_nt64 / k_ntF: the batch-2048 steps) and a
+    small-tile family (k_nt32 / k_ntFs: short tail steps); force each in turn on a ragged batch that
+    spans several row tiles."""
+    from paccmann_polymer_amd import _C
+    old = _C.lib.ppk_nt_small_grid_limit(-1)
+    try:
+        assert _C.lib.ppk_nt_small_grid_limit(limit) == limit
+        check_train_step(params, B, lo, hi, seed)
+    finally:
+        _C.lib.ppk_nt_small_grid_limit(old)
+
+
+def check_train_step(params, B, lo, hi, seed):
     from oracle import stackgru_ref as R
     rng = np.random.default_rng(seed)
     ref, gpu = build_pair(params, seed, torch.float64)

@@ -287,6 +287,56 @@ FA_KERNEL(k_fa_3, 3)
 FA_KERNEL(k_fa_7, 7)
 FA_KERNEL(k_fa_8, 8)
 
+// staging only: the LDS-DMA fill stream of the 64x64 kernel with nothing consuming it (per-CU fill rate)
+template <int NBUF>
+__device__ __forceinline__ void stage_only_body(const float* __restrict__ A, long long lda, const float* __restrict__ B, long long ldb,
+                                                float* __restrict__ C, int M, int N, int K, int aux_nt)
+{
+    constexpr int BM = 64, BN = 64, BK = 32, BUF = (BM + BN) * BK, PPW = 4;
+    __shared__ __align__(1024) float lds[NBUF * BUF];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const int r8 = lane >> 3, pc = lane & 7;
+    const float* ga[2];
+    const float* gb[2];
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        const int row = (wave + 4 * p) * 8 + r8;
+        const int lc = pc ^ ((row >> 1) & 7);
+        int gr = m0 + row; gr = gr < M ? gr : M - 1;
+        ga[p] = A + (long long)gr * lda + lc * 4;
+        int gc = n0 + row; gc = gc < N ? gc : N - 1;
+        gb[p] = B + (long long)gc * ldb + lc * 4;
+    }
+    const int nk = K / BK;
+    int cur = 0;
+    for (int it = 0; it < nk; ++it) {
+        float* la = lds + cur * BUF;
+        float* lb = la + BM * BK;
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            if (aux_nt) __builtin_amdgcn_global_load_lds(ga[p], LDS_PTR(la + (wave + 4 * p) * 256), 16, 0, 2);
+            else __builtin_amdgcn_global_load_lds(ga[p], LDS_PTR(la + (wave + 4 * p) * 256), 16, 0, 0);
+            ga[p] += BK;
+        }
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            if (aux_nt) __builtin_amdgcn_global_load_lds(gb[p], LDS_PTR(lb + (wave + 4 * p) * 256), 16, 0, 2);
+            else __builtin_amdgcn_global_load_lds(gb[p], LDS_PTR(lb + (wave + 4 * p) * 256), 16, 0, 0);
+            gb[p] += BK;
+        }
+        if (it >= NBUF - 1) wait_vmcnt<(NBUF - 1) * PPW>();
+        cur = cur + 1 == NBUF ? 0 : cur + 1;
+    }
+    wait_vmcnt<0>();
+    __syncthreads();
+    if (tid == 0) C[(long long)blockIdx.y * gridDim.x + blockIdx.x] = lds[17];
+}
+__global__ __launch_bounds__(256) void k_stage4(const float* A, long long lda, const float* B, long long ldb, float* C, int M, int N, int K, int nt)
+{ stage_only_body<4>(A, lda, B, ldb, C, M, N, K, nt); }
+__global__ __launch_bounds__(256) void k_stage2(const float* A, long long lda, const float* B, long long ldb, float* C, int M, int N, int K, int nt)
+{ stage_only_body<2>(A, lda, B, ldb, C, M, N, K, nt); }
+
 // the baseline from the library (register staged, guarded) for comparison
 __global__ __launch_bounds__(256) void k_base(const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ C, int M, int N, int K)
 {
@@ -380,7 +430,7 @@ static void bench(const char* name, F launch, float* C, int M, int N, int K, int
 
 int main()
 {
-    const int shapes[][3] = {{2048, 1536, 512}, {2048, 3072, 512}, {64, 64, 512}};
+    const int shapes[][3] = {{2048, 1536, 512}, {2048, 512, 1536}, {64, 512, 1536}, {64, 64, 512}};
     for (auto& s : shapes) {
         const int M = s[0], N = s[1], K = s[2];
         hA.resize((size_t)M * K); hB.resize((size_t)N * K);
@@ -396,6 +446,24 @@ int main()
         bench("glds 64x64 3buf", [&] { launch_glds<64, 3>(g64, A, B, C, M, N, K); }, C, M, N, K, g64.x * g64.y);
         bench("glds 64x64 4buf", [&] { launch_glds<64, 4>(g64, A, B, C, M, N, K); }, C, M, N, K, g64.x * g64.y);
         bench("glds 128x64 3buf", [&] { launch_glds<128, 3>(g128, A, B, C, M, N, K); }, C, M, N, K, g128.x * g128.y);
+        {
+            hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+            for (int v = 0; v < 4; ++v) {
+                float ms;
+                for (int rep = 0; rep < 2; ++rep) {
+                    CK(hipEventRecord(e0));
+                    for (int i = 0; i < 20; ++i) {
+                        if (v < 2) k_stage4<<<g64, 256>>>(A, K, B, K, C, M, N, K, v & 1);
+                        else k_stage2<<<g64, 256>>>(A, K, B, K, C, M, N, K, v & 1);
+                    }
+                    CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+                    CK(hipEventElapsedTime(&ms, e0, e1));
+                }
+                const double bytes = (double)g64.x * g64.y * (64 + 64) * K * 4.0;
+                printf("  stage-only %s %s   %7.1f us  %.2f TB/s  %.1f GB/s per CU (blocks %d)\n", v < 2 ? "4buf" : "2buf", (v & 1) ? "nt " : "def", ms / 20 * 1e3,
+                       bytes / (ms / 20 * 1e-3) / 1e12, bytes / (ms / 20 * 1e-3) / 1e9 / (g64.x * g64.y < 256 ? g64.x * g64.y : 256), g64.x * g64.y);
+            }
+        }
         const dim3 gf((N + 95) / 96, (M + 127) / 128);
         bench("F 128x96 2buf plain", [&] { k_f_2<<<gf, 256>>>(A, K, B, K, C, N, M, N, K, 96, 32); }, C, M, N, K, gf.x * gf.y);
         bench("F 128x96 3buf plain", [&] { k_f_3<<<gf, 256>>>(A, K, B, K, C, N, M, N, K, 96, 32); }, C, M, N, K, gf.x * gf.y);

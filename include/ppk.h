@@ -130,7 +130,8 @@ int ppk_gemm_f32(int transA, int transB, int64_t M, int64_t N, int64_t K, float 
  * whose big-tile grid has at most `limit` tiles run on the small-tile kernels (one 32-row tile per
  * workgroup, K split over its four waves) that keep short packed-batch tail steps — and the
  * reference's own <= 21-sequence bundles (reactions_vae.py:52-59) — off the single-CU latency floor.
- * limit < 0 only queries; returns the value in force (default 128 = half the CUs). */
+ * limit == -1 restores the defaults (224 tiles for the 64 x 64 family, 128 for the gate-layout family, from MI355X kernel traces);
+ * limit < -1 only queries; returns the value in force. */
 int64_t ppk_nt_small_grid_limit(int64_t limit);
 
 /* ---- K1: stack-augmented GRU sequence (packed, length-sorted batch) -------

@@ -539,13 +539,27 @@ __global__ __launch_bounds__(256) void k_ntFs(const NtBatch nb)
 
 inline long long cdiv(long long a, long long b) { return (a + b - 1) / b; }
 
-// big-tile launches with at most this many tiles go to the small-tile kernels
-// (env PPK_NT_SMALL or ppk_nt_small_grid_limit(); measured best at half the CU count)
-long long g_small_limit = -1;
+// Which tile family runs a launch: the small-tile kernels take over when the big-tile grid has at
+// most this many tiles (rocprofv3 traces of the batch-2048 step, profiles/: below ~half a tile per CU a
+// big-tile launch sits on the latency floor of one tile's K loop, ~34 us at K = 1536, while 32-row
+// tiles finish in ~12 us; above it the small tiles lose to their 2-4x higher L2 operand traffic).
+// ppk_nt_small_grid_limit(L >= 0) or env PPK_NT_SMALL / PPK_NTF_SMALL override (tests, tuning).
+long long g_small_limit = -2, g_small_limit_f = -2;
 long long small_grid_limit()
 {
-    if (g_small_limit < 0) { const char* e = getenv("PPK_NT_SMALL"); g_small_limit = e ? atoll(e) : 128; }
+    if (g_small_limit == -2) { const char* e = getenv("PPK_NT_SMALL"); g_small_limit = e ? atoll(e) : -1; }
     return g_small_limit;
+}
+bool use_small_64(long long tiles64)
+{
+    const long long lim = small_grid_limit();
+    return tiles64 <= (lim >= 0 ? lim : 224);
+}
+bool use_small_F(long long tilesF)
+{
+    if (g_small_limit_f == -2) { const char* e = getenv("PPK_NTF_SMALL"); g_small_limit_f = e ? atoll(e) : -1; }
+    const long long lim = small_grid_limit() >= 0 && g_small_limit_f < 0 ? small_grid_limit() : g_small_limit_f;
+    return tilesF <= (lim >= 0 ? lim : 128);
 }
 
 int check_common(const ppk::NtProblem& p, const char* who)
@@ -573,7 +587,7 @@ int gemm_nt64(const NtProblem* ps, int count, hipStream_t stream)
 {
     if (count < 1 || count > NT_MAX_GROUP) PPK_FAIL(PPK_ERR_UNSUP, "gemm_nt64: 1..%d problems", NT_MAX_GROUP);
     NtBatch nb;
-    long long gx = 0, gy = 0, gx32 = 0, gy32 = 0, tiles64 = 0, tilesF = 0;
+    long long gx = 0, gy = 0, gx32 = 0, gy32 = 0, tiles64 = 0, tiles32 = 0, tilesF = 0, tilesFs = 0, kmax = 0;
     double flops = 0;
     for (int i = 0; i < count; ++i) {
         const NtProblem& p = ps[i];
@@ -594,12 +608,14 @@ int gemm_nt64(const NtProblem* ps, int count, hipStream_t stream)
         gx32 = gx32 > cdiv(p.N, 32) ? gx32 : cdiv(p.N, 32);
         gy32 = gy32 > cdiv(p.M, 32) ? gy32 : cdiv(p.M, 32);
         tiles64 += cdiv(p.N, 64) * cdiv(p.M, 64);
+        tiles32 += cdiv(p.N, 32) * cdiv(p.M, 32);
+        kmax = kmax > p.K ? kmax : p.K;
         flops += 2.0 * (double)p.M * (double)p.N * (double)p.K;
     }
-    (void)tilesF;
+    (void)tilesF; (void)tilesFs; (void)tiles32; (void)kmax;
     if (gx == 0 || gy == 0) return PPK_OK;
-    if (tiles64 <= small_grid_limit()) {
-        // fewer tiles than half the CUs: 32 x 32 tiles with K split over the waves
+    if (use_small_64(tiles64)) {
+        // 32 x 32 tiles with K split over the waves
         ProfScope prof(PK_GEMM_NT32, flops, stream);
         k_nt32<<<dim3((unsigned)gx32, (unsigned)gy32, (unsigned)count), dim3(256), 0, stream>>>(nb);
         PPK_CHECK_LAUNCH("k_nt32");
@@ -615,7 +631,7 @@ int gemm_ntF(const NtProblem* ps, int count, hipStream_t stream)
 {
     if (count < 1 || count > NT_MAX_GROUP) PPK_FAIL(PPK_ERR_UNSUP, "gemm_ntF: 1..%d problems", NT_MAX_GROUP);
     NtBatch nb;
-    long long gx = 0, gy = 0, gx32 = 0, gy32 = 0, tiles64 = 0, tilesF = 0;
+    long long gx = 0, gy = 0, gx32 = 0, gy32 = 0, tiles64 = 0, tiles32 = 0, tilesF = 0, tilesFs = 0, kmax = 0;
     double flops = 0;
     for (int i = 0; i < count; ++i) {
         const NtProblem& p = ps[i];
@@ -637,11 +653,13 @@ int gemm_ntF(const NtProblem* ps, int count, hipStream_t stream)
         gy = gy > cdiv(p.M, 128) ? gy : cdiv(p.M, 128);
         gy32 = gy32 > cdiv(p.M, 32) ? gy32 : cdiv(p.M, 32);
         tilesF += cdiv(p.H, 32) * cdiv(p.M, 128);
+        tilesFs += cdiv(p.H, 32) * cdiv(p.M, 32);
+        kmax = kmax > p.K ? kmax : p.K;
         flops += 2.0 * (double)p.M * (double)p.N * (double)p.K;
     }
-    (void)gx32; (void)tiles64;
+    (void)gx32; (void)tiles64; (void)tiles32; (void)tilesFs; (void)kmax;
     if (gx == 0 || gy == 0) return PPK_OK;
-    if (tilesF <= small_grid_limit()) {
+    if (use_small_F(tilesF)) {
         ProfScope prof(PK_GEMM_NTFS, flops, stream);
         k_ntFs<<<dim3((unsigned)gx, (unsigned)gy32, (unsigned)count), dim3(256), 0, stream>>>(nb);
         PPK_CHECK_LAUNCH("k_ntFs");
@@ -658,10 +676,11 @@ int gemm_ntF(const NtProblem* ps, int count, hipStream_t stream)
 extern "C" {
 
 // Tuning / test hook: NT GEMM launches whose big-tile grid has at most `limit` tiles use the
-// small-tile kernels (K split over the waves).  limit < 0 only queries.  Returns the value in force.
+// small-tile kernels (K split over the waves); -1 restores the built-in thresholds (the default);
+// any other negative value only queries.  Returns the value in force.
 int64_t ppk_nt_small_grid_limit(int64_t limit)
 {
-    if (limit >= 0) g_small_limit = limit;
+    if (limit >= -1) g_small_limit = limit;
     return small_grid_limit();
 }
 

@@ -66,7 +66,7 @@ def test_train_step_both_tile_families(params, B, lo, hi, seed, limit):
     small-tile family (k_nt32 / k_ntFs: short tail steps); force each in turn on a ragged batch that
     spans several row tiles."""
     from paccmann_polymer_amd import _C
-    old = _C.lib.ppk_nt_small_grid_limit(-1)
+    old = _C.lib.ppk_nt_small_grid_limit(-2)
     try:
         assert _C.lib.ppk_nt_small_grid_limit(limit) == limit
         check_train_step(params, B, lo, hi, seed)

@@ -22,7 +22,7 @@ print('kernel time per step (ms), launches per step')
 for k, v in sorted(tot.items(), key=lambda x: -x[1])[:16]:
     print('  %-44s %8.2f %8.1f' % (k, v / 1e3 / steps, cnt[k] / steps))
 print('  %-44s %8.2f' % ('TOTAL', sum(tot.values()) / 1e3 / steps))
-for kn in ('k_nt64', 'k_ntF'):
+for kn in ('k_nt64', 'k_ntF', 'k_nt32', 'k_ntFs'):
     shapes = sorted({(k[1], k[3]) for k in agg if k[0] == kn})
     for gx, gz in shapes:
         items = {k[2]: v for k, v in agg.items() if k[0] == kn and k[1] == gx and k[3] == gz}

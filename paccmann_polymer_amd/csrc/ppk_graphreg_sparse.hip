@@ -33,89 +33,124 @@ __device__ __forceinline__ float reg_f(int sgn, float di, float dj, float& dfa)
 }
 __device__ __forceinline__ int sgn_cmp(float a, float b) { return (a > b) - (a < b); }
 
-// one wave per local anchor row: distances of its incident edges, G in CSR order, running max
+// All three phases are parallel over CSR ENTRIES, not over anchors: relation graphs are power-law
+// (a hub with thousands of neighbours would otherwise serialise a whole kernel behind one wave).
+
+// largest p in [lo, hi) with rowptr[p] <= e  (the row that holds CSR entry e)
+__device__ __forceinline__ long long row_of(const long long* __restrict__ rowptr, long long lo, long long hi, long long e)
+{
+    while (hi - lo > 1) {
+        const long long mid = (lo + hi) >> 1;
+        if (rowptr[mid] <= e) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
+constexpr int DIST_CHUNK = 16;     // CSR entries per wave in the distance pass (4 at a time, 16 lanes each)
+constexpr int DZ_CHUNK = 256;      // CSR entries per wave in the gradient pass
+
+// one wave per DIST_CHUNK entries of the local anchors: distance of each entry's edge, G in CSR order, running max.
+// A quarter wave (16 lanes) owns one entry, so four random 1 KB latent rows are in flight per wave instruction.
 __global__ __launch_bounds__(256) void k_sp_dist(const float* __restrict__ z, long long ldz, int zdim,
                                                  const long long* __restrict__ rowptr, const long long* __restrict__ col,
                                                  const long long* __restrict__ eid, const float* __restrict__ g, long long E,
                                                  long long a0, long long a1, float* __restrict__ dcsr, float* __restrict__ gcsr,
                                                  unsigned int* __restrict__ Mbits)
 {
-    const int lane = threadIdx.x & 63;
-    const long long w0 = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63, sub = lane >> 4, l16 = lane & 15;
+    const long long w = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const long long e_end = rowptr[a1];
+    const long long j0 = rowptr[a0] + w * DIST_CHUNK;
+    if (j0 >= e_end) return;
+    const bool vec = !(zdim & 3) && !(ldz & 3) && !((uintptr_t)z & 15);
     float mx = 0.f;
-    for (long long a = a0 + w0; a < a1; a += (long long)gridDim.x * 4) {
-        const float* za = z + a * ldz;
-        for (long long j = rowptr[a]; j < rowptr[a + 1]; ++j) {
+    long long a = row_of(rowptr, a0, a1, j0);            // one search per wave, then walk
+#pragma unroll
+    for (int step = 0; step < DIST_CHUNK / 4; ++step) {
+        const long long j = j0 + step * 4 + sub;
+        float acc = 0.f;
+        const bool on = j < e_end;
+        if (on) {
+            while (j >= rowptr[a + 1]) ++a;
+            const float* za = z + a * ldz;
             const float* zx = z + col[j] * ldz;
-            float acc = 0.f;
-            for (int k = lane; k < zdim; k += 64) {
-                const float d = za[k] - zx[k];
-                acc = fmaf(d, d, acc);
+            if (vec) {
+                for (int k = l16 * 4; k < zdim; k += 64) {
+                    const f32x4 p = *reinterpret_cast<const f32x4*>(za + k), q = *reinterpret_cast<const f32x4*>(zx + k);
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) { const float d = p[c] - q[c]; acc = fmaf(d, d, acc); }
+                }
+            } else {
+                for (int k = l16; k < zdim; k += 16) { const float d = za[k] - zx[k]; acc = fmaf(d, d, acc); }
             }
-            acc = ppk_wave_sum(acc);
-            const float dist = sqrtf(acc);
-            if (lane == 0) {
-                dcsr[j] = dist;
-                gcsr[j] = g[eid[j] % E];
-            }
-            mx = fmaxf(mx, dist);
         }
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);       // within the 16-lane group
+        const float dist = sqrtf(acc);
+        if (on && l16 == 0) {
+            dcsr[j] = dist;
+            gcsr[j] = g[eid[j] % E];
+        }
+        mx = fmaxf(mx, dist);
     }
-    if (lane == 0 && mx > 0.f) atomicMax(Mbits, __float_as_uint(mx));
+    mx = ppk_wave_max(mx);
+    // same-address atomics serialise (~12 ns each): only waves that can still raise the maximum issue one
+    if (lane == 0 && mx > 0.f && __float_as_uint(mx) > __hip_atomic_load(Mbits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+        atomicMax(Mbits, __float_as_uint(mx));
 }
 
-// one wave per local anchor: T[j] (d sum f / d D owned by this anchor for its entry j) and the anchor's partial S
+// one LANE per CSR entry x of a local anchor a: T[x] (d sum f / d D owned by this anchor for its entry x);
+// the entries' contributions to S are summed per wave in a fixed order (Spart[wave]).
 __global__ __launch_bounds__(256) void k_sp_terms(const long long* __restrict__ rowptr, const long long* __restrict__ col,
                                                   const float* __restrict__ dcsr, const float* __restrict__ gcsr,
                                                   long long a0, long long a1, float* __restrict__ T, double* __restrict__ Spart)
 {
-    const int lane = threadIdx.x & 63;
-    const long long w0 = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    for (long long a = a0 + w0; a < a1; a += (long long)gridDim.x * 4) {
+    const long long gw = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const long long e = rowptr[a0] + (long long)blockIdx.x * 256 + threadIdx.x;
+    double S = 0.0;
+    if (e < rowptr[a1]) {
+        const long long a = row_of(rowptr, a0, a1, e);
         const long long j0 = rowptr[a];
         const int deg = (int)(rowptr[a + 1] - j0);
-        double S = 0.0;
-        for (int x = lane; x < deg; x += 64) {
-            const long long idx = col[j0 + x];
-            const float dx = dcsr[j0 + x], gx = gcsr[j0 + x];
-            float t = 0.f, Sx = 0.f;
-            if (idx < a) {
-                // column raster, x plays i: partners r with id > id_x
-                for (int y = 0; y < deg; ++y) {
-                    if (col[j0 + y] <= idx) continue;
-                    float dfa;
-                    Sx += reg_f(sgn_cmp(gx, gcsr[j0 + y]), dx, dcsr[j0 + y], dfa);
-                    t += dfa;
-                }
+        const long long idx = col[e];
+        const float dx = dcsr[e], gx = gcsr[e];
+        float t = 0.f, Sx = 0.f;
+        if (idx < a) {
+            // column raster, x plays i: partners r with id > id_x
+            for (int y = 0; y < deg; ++y) {
+                if (col[j0 + y] <= idx) continue;
+                float dfa;
+                Sx += reg_f(sgn_cmp(gx, gcsr[j0 + y]), dx, dcsr[j0 + y], dfa);
+                t += dfa;
             }
-            // column raster, x plays r: partners i with id < a and id < id_x
+        }
+        // column raster, x plays r: partners i with id < a and id < id_x
+        for (int y = 0; y < deg; ++y) {
+            const long long idy = col[j0 + y];
+            if (idy >= a || idy >= idx) continue;
+            float dfa;
+            (void)reg_f(sgn_cmp(gcsr[j0 + y], gx), dcsr[j0 + y], dx, dfa);
+            t -= dfa;
+        }
+        if (idx > a) {
             for (int y = 0; y < deg; ++y) {
                 const long long idy = col[j0 + y];
-                if (idy >= a || idy >= idx) continue;
+                const float dy = dcsr[j0 + y];
                 float dfa;
-                (void)reg_f(sgn_cmp(gcsr[j0 + y], gx), dcsr[j0 + y], dx, dfa);
-                t -= dfa;
-            }
-            if (idx > a) {
-                for (int y = 0; y < deg; ++y) {
-                    const long long idy = col[j0 + y];
-                    const float dy = dcsr[j0 + y];
-                    float dfa;
-                    if (idy > idx) {                       // row raster, x plays j, y plays c
-                        Sx += reg_f(sgn_cmp(gx, dy), dx, dy, dfa);
-                        t += dfa;
-                    } else if (idy > a && idy < idx) {     // row raster, x plays c, y plays j
-                        (void)reg_f(sgn_cmp(gcsr[j0 + y], dx), dy, dx, dfa);
-                        t -= dfa;
-                    }
+                if (idy > idx) {                       // row raster, x plays j, y plays c
+                    Sx += reg_f(sgn_cmp(gx, dy), dx, dy, dfa);
+                    t += dfa;
+                } else if (idy > a && idy < idx) {     // row raster, x plays c, y plays j
+                    (void)reg_f(sgn_cmp(gcsr[j0 + y], dx), dy, dx, dfa);
+                    t -= dfa;
                 }
             }
-            T[j0 + x] = t;
-            S += (double)Sx;
         }
-        S = ppk_wave_sum_d(S);
-        if (lane == 0) Spart[a - a0] = S;
+        T[e] = t;
+        S = (double)Sx;
     }
+    S = ppk_wave_sum_d(S);
+    if ((threadIdx.x & 63) == 0) Spart[gw] = S;
 }
 
 // S = sum of anchor partials in fixed order (single block), S_out[0] = S
@@ -134,63 +169,148 @@ __global__ void k_sp_loss(const double* __restrict__ S, const unsigned int* __re
     loss[0] = (float)(S[0] / (double)__uint_as_float(Mbits[0]));
 }
 
-// one wave per node p in [0, N): partial dz from the terms owned by local anchors
-__global__ __launch_bounds__(256) void k_sp_dz(const float* __restrict__ z, long long ldz, int zdim, long long N,
-                                               const long long* __restrict__ rowptr, const long long* __restrict__ col,
-                                               const long long* __restrict__ rev, const float* __restrict__ dcsr,
-                                               const float* __restrict__ T, long long a0, long long a1,
-                                               const double* __restrict__ S, const unsigned int* __restrict__ Mbits,
-                                               const float* __restrict__ dloss, float* __restrict__ dz, long long lddz)
+// Gradient pass 0: one lane per CSR entry j of row p (all nodes): coef[j] such that
+// dz[p] = sum_j coef[j] (z_p - z_col[j]); zero when neither endpoint is a local anchor.
+__global__ __launch_bounds__(256) void k_sp_coef(long long N, const long long* __restrict__ rowptr, const long long* __restrict__ col,
+                                                 const long long* __restrict__ rev, const float* __restrict__ dcsr,
+                                                 const float* __restrict__ T, long long a0, long long a1,
+                                                 const double* __restrict__ S, const unsigned int* __restrict__ Mbits,
+                                                 const float* __restrict__ dloss, float* __restrict__ coef)
 {
-    const int lane = threadIdx.x & 63;
-    const long long w0 = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const long long j = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (j >= rowptr[N]) return;
     const float up = dloss[0];
     const float M = __uint_as_float(Mbits[0]);
     const float invM = 1.0f / M;
     const float gmax = (float)(-S[0] / ((double)M * (double)M));
-    for (long long p = w0; p < N; p += (long long)gridDim.x * 4) {
-        const bool own_p = p >= a0 && p < a1;
-        const float* zp = z + p * ldz;
-        for (int k0 = 0; k0 < zdim; k0 += 64) {
-            const int k = k0 + lane;
-            const float zpk = k < zdim ? zp[k] : 0.f;
-            float acc = 0.f;
-            for (long long j = rowptr[p]; j < rowptr[p + 1]; ++j) {
-                const long long a = col[j];
-                const bool own_a = a >= a0 && a < a1;
-                if (!own_p && !own_a) continue;
-                const long long rj = rev[j];
-                const float d = own_p ? dcsr[j] : dcsr[rj];
-                if (d == 0.f) continue;
-                float w = 0.f;
-                if (own_p) w += T[j];
-                if (own_a) w += T[rj];
-                w *= invM;
-                // gradient through the normaliser: applied once per undirected edge, by the owner of its lower endpoint
-                if (d == M && ((p < a) ? own_p : own_a)) w += gmax;
-                if (k < zdim) acc = fmaf(up * w / d, zpk - z[a * ldz + k], acc);
+    const long long p = row_of(rowptr, 0, N, j);
+    const long long a = col[j];
+    const bool own_p = p >= a0 && p < a1, own_a = a >= a0 && a < a1;
+    float c = 0.f;
+    if (own_p || own_a) {
+        const long long rj = rev[j];
+        const float d = own_p ? dcsr[j] : dcsr[rj];
+        if (d != 0.f) {
+            float w = 0.f;
+            if (own_p) w += T[j];
+            if (own_a) w += T[rj];
+            w *= invM;
+            // gradient through the normaliser: applied once per undirected edge, by the owner of its lower endpoint
+            if (d == M && ((p < a) ? own_p : own_a)) w += gmax;
+            c = up * w / d;
+        }
+    }
+    coef[j] = c;
+}
+
+// Gradient pass 1: one wave per DZ_CHUNK consecutive CSR entries.  A row that lies inside the chunk is finished
+// here; a row that crosses a chunk border leaves a partial in head[c] (row began in an earlier chunk) or
+// tail[c] (row continues in the next chunk), combined in a fixed order by pass 2.  Coefficients and column
+// ids are fetched 64 at a time (one per lane) and broadcast, so the only dependent loads are the row gathers.
+__global__ __launch_bounds__(256) void k_sp_dz(const float* __restrict__ z, long long ldz, int zdim, long long N,
+                                               const long long* __restrict__ rowptr, const long long* __restrict__ col,
+                                               const float* __restrict__ coef, float* __restrict__ dz, long long lddz,
+                                               float* __restrict__ head, float* __restrict__ tail)
+{
+    const int lane = threadIdx.x & 63;
+    const long long c = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const long long nnz = rowptr[N];
+    const long long e0 = c * DZ_CHUNK;
+    if (e0 >= nnz) return;
+    const long long e1 = e0 + DZ_CHUNK < nnz ? e0 + DZ_CHUNK : nnz;
+    for (int kb = 0; kb < zdim; kb += 256) {
+        long long p = row_of(rowptr, 0, N, e0);
+        long long rend = rowptr[p + 1];
+        bool before = rowptr[p] < e0;
+        float acc[4] = {0.f, 0.f, 0.f, 0.f}, zp[4];
+        auto load_zp = [&]() {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { const int k = kb + lane + 64 * q; zp[q] = k < zdim ? z[p * ldz + k] : 0.f; }
+        };
+        auto store = [&](float* dst) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { const int k = kb + lane + 64 * q; if (k < zdim) dst[k] = acc[q]; acc[q] = 0.f; }
+        };
+        load_zp();
+        for (long long jb = e0; jb < e1; jb += 64) {
+            const long long jm = jb + lane;
+            const float my_c = jm < e1 ? coef[jm] : 0.f;
+            const long long my_a = jm < e1 ? col[jm] : 0;
+            const int cnt = (int)(e1 - jb < 64 ? e1 - jb : 64);
+            for (int i = 0; i < cnt; ++i) {
+                const long long j = jb + i;
+                if (j >= rend) {                               // row p ended inside the chunk
+                    store(before ? head + c * zdim : dz + p * lddz);
+                    before = false;
+                    do { ++p; rend = rowptr[p + 1]; } while (j >= rend);
+                    load_zp();
+                }
+                const float cf = __shfl(my_c, i, 64);
+                if (cf == 0.f) continue;
+                const long long a = __shfl(my_a, i, 64);
+                const float* za = z + a * ldz;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { const int k = kb + lane + 64 * q; if (k < zdim) acc[q] = fmaf(cf, zp[q] - za[k], acc[q]); }
             }
-            if (k < zdim) dz[p * lddz + k] = acc;
+        }
+        if (rend > e1) store(before ? head + c * zdim : tail + c * zdim);      // row continues in the next chunk
+        else store(before ? head + c * zdim : dz + p * lddz);                  // row ends with the chunk
+    }
+}
+// Gradient pass 2: one wave per node: rows that cross chunk borders are tail[first chunk] + head[following chunks]
+// (fixed order); nodes without any entry get zeros.
+__global__ __launch_bounds__(256) void k_sp_dz_fix(int zdim, long long N, const long long* __restrict__ rowptr,
+                                                   const float* __restrict__ head, const float* __restrict__ tail,
+                                                   float* __restrict__ dz, long long lddz)
+{
+    const int lane = threadIdx.x & 63;
+    const long long w0 = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    for (long long p = w0; p < N; p += (long long)gridDim.x * 4) {
+        const long long r0 = rowptr[p], r1 = rowptr[p + 1];
+        if (r1 <= r0) {
+            for (int k = lane; k < zdim; k += 64) dz[p * lddz + k] = 0.f;
+            continue;
+        }
+        const long long cf = r0 / DZ_CHUNK, cl = (r1 - 1) / DZ_CHUNK;
+        if (cf == cl) continue;
+        for (int k = lane; k < zdim; k += 64) {
+            float acc = tail[cf * zdim + k];
+            for (long long c = cf + 1; c <= cl; ++c) acc += head[c * zdim + k];
+            dz[p * lddz + k] = acc;
         }
     }
 }
 
-struct SpWs { float* dcsr; float* gcsr; float* T; double* Spart; double* S; unsigned int* Mbits; };
-size_t sp_ws_bytes(int64_t N, int64_t nnz)
+struct SpWs { float* dcsr; float* gcsr; float* T; double* Spart; double* S; unsigned int* Mbits; float* coef; float* head; float* tail; };
+inline size_t sp_nwaves(int64_t nnz) { return (size_t)(nnz + 255) / 256 * 4; }              // waves of the terms pass
+inline size_t sp_nchunks(int64_t nnz) { return (size_t)(nnz + DZ_CHUNK - 1) / DZ_CHUNK; }   // waves of the gradient pass
+size_t sp_ws_bytes(int64_t N, int64_t nnz, int64_t zdim)
 {
-    return 3 * ppk_align_up(sizeof(float) * (size_t)nnz, 256) + ppk_align_up(sizeof(double) * (size_t)N, 256) + 2 * 256;
+    (void)N;
+    return 3 * ppk_align_up(sizeof(float) * (size_t)nnz, 256) + ppk_align_up(sizeof(double) * sp_nwaves(nnz), 256) + 2 * 256 +
+           (zdim > 0 ? ppk_align_up(sizeof(float) * (size_t)nnz, 256) : 0) +
+           2 * ppk_align_up(sizeof(float) * sp_nchunks(nnz) * (size_t)zdim, 256);
 }
-SpWs sp_carve(void* ws, int64_t N, int64_t nnz)
+SpWs sp_carve(void* ws, int64_t N, int64_t nnz, int64_t zdim)
 {
+    (void)N;
     char* cur = (char*)ws;
     SpWs w;
     w.dcsr = (float*)ppk_carve(cur, sizeof(float) * (size_t)nnz);
     w.gcsr = (float*)ppk_carve(cur, sizeof(float) * (size_t)nnz);
     w.T = (float*)ppk_carve(cur, sizeof(float) * (size_t)nnz);
-    w.Spart = (double*)ppk_carve(cur, sizeof(double) * (size_t)N);
+    w.Spart = (double*)ppk_carve(cur, sizeof(double) * sp_nwaves(nnz));
     w.S = (double*)ppk_carve(cur, 256);
     w.Mbits = (unsigned int*)ppk_carve(cur, 256);
+    w.coef = (float*)ppk_carve(cur, sizeof(float) * (size_t)nnz);
+    w.head = (float*)ppk_carve(cur, sizeof(float) * sp_nchunks(nnz) * (size_t)zdim);
+    w.tail = (float*)ppk_carve(cur, sizeof(float) * sp_nchunks(nnz) * (size_t)zdim);
     return w;
+}
+inline unsigned blocks_for(long long waves)
+{
+    long long b = (waves + 3) / 4;
+    return (unsigned)(b < 1 ? 1 : b);
 }
 inline unsigned wave_grid(long long rows)
 {
@@ -205,7 +325,7 @@ int sp_check(const void* z, int64_t ldz, int64_t N, int64_t zdim, int64_t E, con
     if (N < 1 || zdim < 1 || E < 1 || ldz < zdim || a0 < 0 || a1 > N || a0 >= a1)
         PPK_FAIL(PPK_ERR_SHAPE, "graphreg_sparse: bad sizes (N=%lld E=%lld zdim=%lld anchors [%lld,%lld))",
                  (long long)N, (long long)E, (long long)zdim, (long long)a0, (long long)a1);
-    if (ws_bytes < sp_ws_bytes(N, 2 * E)) PPK_FAIL(PPK_ERR_WS, "graphreg_sparse: workspace too small");
+    if (ws_bytes < sp_ws_bytes(N, 2 * E, zdim)) PPK_FAIL(PPK_ERR_WS, "graphreg_sparse: workspace too small");
     if ((uintptr_t)ws & 255) PPK_FAIL(PPK_ERR_ALIGN, "graphreg_sparse: workspace must be 256-B aligned");
     return PPK_OK;
 }
@@ -214,10 +334,10 @@ int sp_check(const void* z, int64_t ldz, int64_t N, int64_t zdim, int64_t E, con
 
 extern "C" {
 
-size_t ppk_graphreg_sparse_workspace_bytes(int64_t N, int64_t E)
+size_t ppk_graphreg_sparse_workspace_bytes(int64_t N, int64_t E, int64_t zdim)
 {
-    if (N < 1 || E < 1) return 0;
-    return sp_ws_bytes(N, 2 * E);
+    if (N < 1 || E < 1 || zdim < 1) return 0;
+    return sp_ws_bytes(N, 2 * E, zdim);
 }
 
 // Phase 1: distances of the edges incident to anchors [a0, a1), G into CSR order and the local max.
@@ -230,11 +350,11 @@ int ppk_graphreg_sparse_dist(const float* z, int64_t ldz, int64_t N, int64_t zdi
     int rc = sp_check(z, ldz, N, zdim, E, rowptr, col, a0, a1, workspace, ws_bytes);
     if (rc) return rc;
     if (!g || !eid) PPK_FAIL(PPK_ERR_NULL, "graphreg_sparse_dist: null pointer");
-    SpWs w = sp_carve(workspace, N, 2 * E);
+    SpWs w = sp_carve(workspace, N, 2 * E, 0);
     PPK_HIP(hipMemsetAsync(w.Mbits, 0, 256, stream));
     {
         ppk::ProfScope prof(ppk::PK_GRAPHREG_SPARSE, (double)E * 2 * (2.0 * 4 * zdim + 24), stream);
-        k_sp_dist<<<dim3(wave_grid(a1 - a0)), dim3(256), 0, stream>>>(z, ldz, (int)zdim, (const long long*)rowptr, (const long long*)col,
+        k_sp_dist<<<dim3(blocks_for((2 * E + DIST_CHUNK - 1) / DIST_CHUNK)), dim3(256), 0, stream>>>(z, ldz, (int)zdim, (const long long*)rowptr, (const long long*)col,
                                                                       (const long long*)eid, g, E, a0, a1, w.dcsr, w.gcsr, w.Mbits);
     }
     PPK_CHECK_LAUNCH("k_sp_dist");
@@ -242,8 +362,8 @@ int ppk_graphreg_sparse_dist(const float* z, int64_t ldz, int64_t N, int64_t zdi
 }
 
 // device addresses inside the workspace of the max distance (fp32, non-negative) and of the un-normalised sum S (fp64)
-float* ppk_graphreg_sparse_max_ptr(void* workspace, int64_t N, int64_t E) { return (float*)sp_carve(workspace, N, 2 * E).Mbits; }
-double* ppk_graphreg_sparse_sum_ptr(void* workspace, int64_t N, int64_t E) { return sp_carve(workspace, N, 2 * E).S; }
+float* ppk_graphreg_sparse_max_ptr(void* workspace, int64_t N, int64_t E) { return (float*)sp_carve(workspace, N, 2 * E, 0).Mbits; }
+double* ppk_graphreg_sparse_sum_ptr(void* workspace, int64_t N, int64_t E) { return sp_carve(workspace, N, 2 * E, 0).S; }
 
 // Phase 2: per-anchor comparisons -> T, S (local anchors).  loss [1] = S / M (local S; sum S across ranks before
 // ppk_graphreg_sparse_finish when the anchors are sharded).
@@ -252,12 +372,13 @@ int ppk_graphreg_sparse_terms(int64_t N, int64_t E, const int64_t* rowptr, const
 {
     if (!rowptr || !col || !workspace) PPK_FAIL(PPK_ERR_NULL, "graphreg_sparse_terms: null pointer");
     if (N < 1 || E < 1 || a0 < 0 || a1 > N || a0 >= a1) PPK_FAIL(PPK_ERR_SHAPE, "graphreg_sparse_terms: bad sizes");
-    if (ws_bytes < sp_ws_bytes(N, 2 * E)) PPK_FAIL(PPK_ERR_WS, "graphreg_sparse_terms: workspace too small");
-    SpWs w = sp_carve(workspace, N, 2 * E);
-    k_sp_terms<<<dim3(wave_grid(a1 - a0)), dim3(256), 0, stream>>>((const long long*)rowptr, (const long long*)col, w.dcsr, w.gcsr,
-                                                                   a0, a1, w.T, w.Spart);
+    if (ws_bytes < sp_ws_bytes(N, 2 * E, 0)) PPK_FAIL(PPK_ERR_WS, "graphreg_sparse_terms: workspace too small");
+    SpWs w = sp_carve(workspace, N, 2 * E, 0);
+    const long long nwaves = (long long)sp_nwaves(2 * E);
+    k_sp_terms<<<dim3((unsigned)(nwaves / 4)), dim3(256), 0, stream>>>((const long long*)rowptr, (const long long*)col, w.dcsr, w.gcsr,
+                                                                      a0, a1, w.T, w.Spart);
     PPK_CHECK_LAUNCH("k_sp_terms");
-    k_sp_sum<<<dim3(1), dim3(256), 0, stream>>>(w.Spart, a1 - a0, w.S);
+    k_sp_sum<<<dim3(1), dim3(256), 0, stream>>>(w.Spart, nwaves, w.S);
     PPK_CHECK_LAUNCH("k_sp_sum");
     return PPK_OK;
 }
@@ -265,8 +386,8 @@ int ppk_graphreg_sparse_terms(int64_t N, int64_t E, const int64_t* rowptr, const
 int ppk_graphreg_sparse_finish(int64_t N, int64_t E, float* loss, void* workspace, size_t ws_bytes, hipStream_t stream)
 {
     if (!loss || !workspace) PPK_FAIL(PPK_ERR_NULL, "graphreg_sparse_finish: null pointer");
-    if (ws_bytes < sp_ws_bytes(N, 2 * E)) PPK_FAIL(PPK_ERR_WS, "graphreg_sparse_finish: workspace too small");
-    SpWs w = sp_carve(workspace, N, 2 * E);
+    if (ws_bytes < sp_ws_bytes(N, 2 * E, 0)) PPK_FAIL(PPK_ERR_WS, "graphreg_sparse_finish: workspace too small");
+    SpWs w = sp_carve(workspace, N, 2 * E, 0);
     k_sp_loss<<<dim3(1), dim3(1), 0, stream>>>(w.S, w.Mbits, loss);
     PPK_CHECK_LAUNCH("k_sp_loss");
     return PPK_OK;
@@ -281,10 +402,17 @@ int ppk_graphreg_sparse_bwd(const float* z, int64_t ldz, int64_t N, int64_t zdim
     int rc = sp_check(z, ldz, N, zdim, E, rowptr, col, a0, a1, workspace, ws_bytes);
     if (rc) return rc;
     if (!rev || !dloss || !dz || lddz < zdim) PPK_FAIL(PPK_ERR_NULL, "graphreg_sparse_bwd: null pointer / lddz");
-    SpWs w = sp_carve(workspace, N, 2 * E);
-    k_sp_dz<<<dim3(wave_grid(N)), dim3(256), 0, stream>>>(z, ldz, (int)zdim, N, (const long long*)rowptr, (const long long*)col,
-                                                          (const long long*)rev, w.dcsr, w.T, a0, a1, w.S, w.Mbits, dloss, dz, lddz);
+    SpWs w = sp_carve(workspace, N, 2 * E, zdim);
+    {
+        ppk::ProfScope prof(ppk::PK_GRAPHREG_SPARSE, (double)E * 2 * (2.0 * 4 * zdim + 24), stream);
+        k_sp_coef<<<dim3((unsigned)((2 * E + 255) / 256)), dim3(256), 0, stream>>>(
+            N, (const long long*)rowptr, (const long long*)col, (const long long*)rev, w.dcsr, w.T, a0, a1, w.S, w.Mbits, dloss, w.coef);
+        k_sp_dz<<<dim3(blocks_for((long long)sp_nchunks(2 * E))), dim3(256), 0, stream>>>(
+            z, ldz, (int)zdim, N, (const long long*)rowptr, (const long long*)col, w.coef, dz, lddz, w.head, w.tail);
+    }
     PPK_CHECK_LAUNCH("k_sp_dz");
+    k_sp_dz_fix<<<dim3(wave_grid(N)), dim3(256), 0, stream>>>((int)zdim, N, (const long long*)rowptr, w.head, w.tail, dz, lddz);
+    PPK_CHECK_LAUNCH("k_sp_dz_fix");
     return PPK_OK;
 }
 

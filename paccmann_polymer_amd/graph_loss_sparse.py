@@ -66,7 +66,7 @@ class _SparseGraphLoss(torch.autograd.Function):
         N, Z = z.shape
         E = graph.E
         dev = z.device
-        wsb = _lib.ppk_graphreg_sparse_workspace_bytes(N, E)
+        wsb = _lib.ppk_graphreg_sparse_workspace_bytes(N, E, Z)
         ws = _ws(wsb, dev)
         st = _C.stream()
         _C.check(_lib.ppk_graphreg_sparse_dist(_C.p(z), z.stride(0), N, Z, _C.p(graph.g), E, _C.p(graph.rowptr),

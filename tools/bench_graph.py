@@ -1,0 +1,133 @@
+"""Roofline measurements of the gather / segmented-reduce kernels at BASELINE.json configs[2] and [3]
+(SURVEY.md §8d): K6 CSR build + K7 SpMM on a 5 M-edge synthetic molecular graph batch, and K5 sparse
+graph-regularisation loss on a 1 M-node / 10 M-edge synthetic relation graph.
+
+    python tools/bench_graph.py [--small]          (one MI355X; prints one JSON line per kernel)
+
+Timed with torch.cuda events on the current stream (the stream every ppk op is launched on), inputs
+resident in HBM.  `achieved` = algorithmic bytes (SURVEY §8d formulas) / mean launch time.
+"""
+import argparse
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+PEAK_HBM_GBS = 8000.0
+
+
+def timeit(fn, iters=10, warm=2):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters * 1e-3
+
+
+def line(kernel, workload, seconds, nbytes, extra=None):
+    gbs = nbytes / seconds / 1e9
+    d = dict(kernel=kernel, workload=workload, ms=round(seconds * 1e3, 4),
+             roofline=dict(bound='hbm', achieved=round(gbs, 1), peak=PEAK_HBM_GBS, unit='GB/s', frac=round(gbs / PEAK_HBM_GBS, 4),
+                           algorithmic_bytes=int(nbytes)))
+    if extra:
+        d.update(extra)
+    print(json.dumps(d), flush=True)
+
+
+def molecule_batch(rng, n_nodes):
+    """Blocks of 20..60 atoms: a random tree per block plus ~8 % ring-closing bonds; each bond listed once."""
+    sizes = []
+    left = n_nodes
+    while left > 0:
+        s = int(min(left, rng.integers(20, 61)))
+        sizes.append(s)
+        left -= s
+    sizes = np.asarray(sizes)
+    starts = np.concatenate([[0], np.cumsum(sizes)[:-1]])
+    block = np.repeat(np.arange(len(sizes)), sizes)
+    first = starts[block]
+    idx = np.arange(n_nodes)
+    child = idx[idx > first]
+    parent = first[child] + (rng.random(child.size) * (child - first[child])).astype(np.int64)
+    n_ring = int(0.08 * n_nodes)
+    a = rng.integers(0, n_nodes, size=n_ring)
+    b = first[a] + (rng.random(n_ring) * sizes[block[a]]).astype(np.int64)
+    keep = a != b
+    src = np.concatenate([parent, a[keep]])
+    dst = np.concatenate([child, b[keep]])
+    return np.stack([src, dst]).astype(np.int64)
+
+
+def relation_graph(rng, n_nodes, m):
+    """Preferential-attachment-like simple graph: node t links to m earlier nodes drawn towards low indices."""
+    src = np.repeat(np.arange(1, n_nodes, dtype=np.int64), m)
+    dst = (src * rng.random(src.size) ** 1.5).astype(np.int64)
+    lo, hi = np.minimum(src, dst), np.maximum(src, dst)
+    key = np.unique(lo * n_nodes + hi)
+    key = key[(key // n_nodes) != (key % n_nodes)]
+    return np.stack([key // n_nodes, key % n_nodes]).astype(np.int64)
+
+
+def config3(small):
+    from paccmann_polymer_amd import gcn
+    rng = np.random.default_rng(0)
+    N = 240_000 if small else 2_400_000
+    F = 256
+    bonds = molecule_batch(rng, N)
+    ei = torch.tensor(np.concatenate([bonds, bonds[::-1]], axis=1)).cuda()          # symmetrised: directed edges
+    E = int(ei.shape[1])
+    x = torch.randn(N, F, device='cuda')
+    wl = f'configs[2]: GCN message passing, N={N} nodes, E={E} directed edges (+N self loops), F={F}'
+    t_build = timeit(lambda: gcn.CSRGraph(ei, N), iters=3, warm=1)
+    line('K6 csr_build (forward + reverse CSR, host wrapper)', wl, t_build, 2 * 40.0 * (E + N))
+    g = gcn.CSRGraph(ei, N)
+    nnz = E + N
+    by = nnz * (4 * F + 12) + N * (4 * F + 8)
+    line('K7 k_spmm forward (A_hat x)', wl, timeit(lambda: gcn._spmm(g.fwd, x, g.nnz_cap)), by)
+    line('K7 k_spmm backward (A_hat^T dout, reverse CSR)', wl, timeit(lambda: gcn._spmm(g.rev, x, g.nnz_cap)), by)
+    conv = gcn.GCNConv(F, 512).cuda()
+    with torch.no_grad():
+        t_conv = timeit(lambda: conv(x, g), iters=5)
+    print(json.dumps(dict(kernel='GCNConv(256, 512) forward = K7 + fp32 MFMA GEMM', workload=wl, ms=round(t_conv * 1e3, 3),
+                          gemm_tflops=round(2.0 * N * F * 512 / t_conv / 1e12, 1))), flush=True)
+
+
+def config4(small):
+    from paccmann_polymer_amd.graph_loss_sparse import SparseRelationGraph, graph_loss_sparse, _SparseGraphLoss
+    rng = np.random.default_rng(1)
+    N = 100_000 if small else 1_000_000
+    Z = 256
+    und = relation_graph(rng, N, 10)
+    E = int(und.shape[1])
+    attr = torch.tensor(rng.integers(1, 4, size=E).astype(np.float32)).cuda()
+    graph = SparseRelationGraph(torch.tensor(und).cuda(), attr, N)
+    z = torch.randn(N, Z, device='cuda', requires_grad=True)
+    for share, (a0, a1) in (('all anchors (1 GPU holds the whole graph)', (0, N)), ('1/8 of the anchors (one rank of 8)', (0, N // 8))):
+        wl = f'configs[3]: sparse graph-reg loss, N={N} nodes, E={E} undirected edges, Z={Z}, {share}'
+        frac = (a1 - a0) / N
+        by_f = 2 * E * frac * (2 * 4 * Z + 24) + 3 * 2 * E * frac * 4
+        loss = _SparseGraphLoss.apply(z, graph, a0, a1, False)
+        t_f = timeit(lambda: _SparseGraphLoss.apply(z.detach(), graph, a0, a1, False), iters=5)
+        line('K5 sparse graph loss forward (dist + terms + finish)', wl, t_f, by_f, dict(loss=float(loss)))
+
+        def fb():
+            z.grad = None
+            _SparseGraphLoss.apply(z, graph, a0, a1, False).backward()
+        t_fb = timeit(fb, iters=5)
+        line('K5 sparse graph loss forward + backward', wl, t_fb, 2 * by_f + N * Z * 4)
+
+
+if __name__ == '__main__':
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--small', action='store_true')
+    args = ap.parse_args()
+    config3(args.small)
+    config4(args.small)

@@ -125,9 +125,32 @@ def config4(small):
         line('K5 sparse graph loss forward + backward', wl, t_fb, 2 * by_f + N * Z * 4)
 
 
+def dense(small):
+    """K4 on ONE dense graph (SURVEY config 2: N = 2048, 4.29e9 reference terms): VALU/LDS-bound, priced in
+    f-evaluations per second (each reference term is evaluated in both of its roles: N^2 (N-1) evaluations)."""
+    from paccmann_polymer_amd import graph_loss
+    import networkx as nx
+    for N in ((64, 512) if small else (64, 2048)):
+        g = nx.gnm_random_graph(N, 3 * N, seed=0)
+        G = np.asarray(nx.floyd_warshall_numpy(g))
+        G[np.isinf(G)] = 0
+        Gd = torch.tensor(G, dtype=torch.float64).cuda()
+        z = torch.randn(N, 256, device='cuda', requires_grad=True)
+
+        def fb():
+            z.grad = None
+            graph_loss(z, Gd).backward()
+        t = timeit(fb, iters=5)
+        evals = float(N) * N * (N - 1)
+        print(json.dumps(dict(kernel='K4 dense graph loss forward + backward (k_dist, k_terms, k_dz)',
+                              workload=f'one dense graph N={N}, Z=256 ({int(evals // 2)} reference terms)', ms=round(t * 1e3, 4),
+                              f_evals_per_s=round(evals / t / 1e9, 2), unit='G f-evaluations/s')), flush=True)
+
+
 if __name__ == '__main__':
     ap = argparse.ArgumentParser()
     ap.add_argument('--small', action='store_true')
     args = ap.parse_args()
+    dense(args.small)
     config3(args.small)
     config4(args.small)

@@ -22,15 +22,19 @@ print('kernel time per step (ms), launches per step')
 for k, v in sorted(tot.items(), key=lambda x: -x[1])[:16]:
     print('  %-44s %8.2f %8.1f' % (k, v / 1e3 / steps, cnt[k] / steps))
 print('  %-44s %8.2f' % ('TOTAL', sum(tot.values()) / 1e3 / steps))
+# NT kernels use a 1-D grid of tiles (padded to a multiple of 8): group launches by tile count
 for kn in ('k_nt64', 'k_ntF', 'k_nt32', 'k_ntFs'):
-    shapes = sorted({(k[1], k[3]) for k in agg if k[0] == kn})
-    for gx, gz in shapes:
-        items = {k[2]: v for k, v in agg.items() if k[0] == kn and k[1] == gx and k[3] == gz}
-        n = sum(len(v) for v in items.values())
-        t = sum(sum(v) for v in items.values())
-        print('%s grid.x %d grid.z %d: %d launches, %.2f ms/step' % (kn, gx, gz, n, t / 1e3 / steps))
-        gys = sorted(items)
-        pick = sorted(set([gys[0], gys[len(gys) // 4], gys[len(gys) // 2], gys[3 * len(gys) // 4], gys[-1]]))
-        for gy in pick:
-            v = items[gy]
-            print('     grid.y %4d  n %4d  avg %7.1f us  min %7.1f' % (gy, len(v), sum(v) / len(v), min(v)))
+    items = collections.defaultdict(list)
+    for k, v in agg.items():
+        if k[0] == kn:
+            items[k[1]].extend(v)
+    if not items:
+        continue
+    n = sum(len(v) for v in items.values())
+    t = sum(sum(v) for v in items.values())
+    print('%s: %d launches, %.2f ms/step' % (kn, n, t / 1e3 / steps))
+    sizes = sorted(items)
+    pick = sorted(set(sizes[i * (len(sizes) - 1) // 15] for i in range(16))) if len(sizes) > 16 else sizes
+    for g in pick:
+        v = items[g]
+        print('     tiles %5d  n %4d  avg %7.1f us  min %7.1f' % (g, len(v), sum(v) / len(v), min(v)))

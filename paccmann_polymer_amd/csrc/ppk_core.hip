@@ -2,6 +2,8 @@
 #include "ppk_common.h"
 #include "ppk_kernels.h"
 #include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
 #include <vector>
 
 static thread_local char g_err[512] = "";
@@ -86,17 +88,21 @@ int ppk_prof_collect(double* ms, double* work, int64_t* launches)
 {
     if (!ms || !work || !launches) PPK_FAIL(PPK_ERR_NULL, "prof_collect: null pointer");
     for (int k = 0; k < ppk::PK_COUNT; ++k) { ms[k] = 0; work[k] = 0; launches[k] = 0; }
+    const char* dump = getenv("PPK_PROF_DUMP");          // tuning aid: one "kind work ms" line per launch
+    FILE* df = dump ? fopen(dump, "a") : nullptr;
     for (ProfRec& r : g_prof) {
         float t = 0.f;
         if (hipEventSynchronize(r.b) == hipSuccess && hipEventElapsedTime(&t, r.a, r.b) == hipSuccess) {
             ms[r.kind] += t;
             work[r.kind] += r.work;
             launches[r.kind] += 1;
+            if (df) fprintf(df, "%s %.0f %.5f\n", kKindNames[r.kind], r.work, (double)t);
         }
         (void)hipEventDestroy(r.a);
         (void)hipEventDestroy(r.b);
     }
     g_prof.clear();
+    if (df) fclose(df);
     return PPK_OK;
 }
 

@@ -42,24 +42,26 @@ __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf
 
 // A launch is a 1-D grid over the tiles of up to four problems.  Workgroup ids are dealt round-robin over
 // the 8 XCDs (id % 8), each with its own 4 MiB L2, so the grid index is remapped to give every XCD a
-// CONTIGUOUS run of tiles in n-fastest order: the tiles that share an A row block (and walk K in step)
-// sit on one XCD and fetch it from beyond L2 once, not once per XCD.
+// CONTIGUOUS run of each problem's tiles in n-fastest order: the tiles that share an A row block (and walk
+// K in step) sit on one XCD and fetch it from beyond L2 once, not once per XCD.  Every XCD gets the same
+// share of EVERY problem, so a launch that pairs a short-K problem with a long-K one stays balanced.
 struct NtBatch {
     ppk::NtProblem p[ppk::NT_MAX_GROUP];
     int tn[ppk::NT_MAX_GROUP];              // n-tiles of each problem
-    int toff[ppk::NT_MAX_GROUP + 1];        // first tile of each problem; toff[count] = total
-    int count, chunk;                       // chunk = ceil(total / 8) tiles per XCD
+    int tiles[ppk::NT_MAX_GROUP];           // tiles of each problem
+    int cp[ppk::NT_MAX_GROUP];              // tiles of each problem per XCD = ceil(tiles / 8)
+    int coff[ppk::NT_MAX_GROUP + 1];        // prefix sums of cp: slots of one XCD
+    int count;
 };
 
 // tile of this workgroup: problem z, tile coordinates (tm, tn); false = padding workgroup
 __device__ __forceinline__ bool nt_tile(const NtBatch& nb, int& z, int& tm, int& tn)
 {
-    const int L = blockIdx.x;
-    const int T = (L & 7) * nb.chunk + (L >> 3);
-    if (T >= nb.toff[nb.count]) return false;
+    const int L = blockIdx.x, xcd = L & 7, slot = L >> 3;
     z = 0;
-    while (z + 1 < nb.count && T >= nb.toff[z + 1]) ++z;
-    const int t = T - nb.toff[z];
+    while (z + 1 < nb.count && slot >= nb.coff[z + 1]) ++z;
+    const int t = xcd * nb.cp[z] + (slot - nb.coff[z]);
+    if (t >= nb.tiles[z]) return false;
     tn = t % nb.tn[z];
     tm = t / nb.tn[z];
     return true;
@@ -326,9 +328,11 @@ __device__ __forceinline__ void nt64_body(const ppk::NtProblem& g, float* lds, c
     const int arow = (wm * 32 + li) * BK;
     const int brow = BM * BK + (wn * 32 + li) * BK;
 
-    f32x16 acc;
+    // two independent accumulator chains (even / odd k chunks), added once at the end: a lone wave on a SIMD
+    // cannot issue dependent 32x32x2 MFMAs back to back (1830 instead of 1024 cycles per K tile measured)
+    f32x16 acc, acc1;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    for (int r = 0; r < 16; ++r) { acc[r] = 0.f; acc1[r] = 0.f; }
 
     const int row0 = m0 + wm * 32, col0 = n0 + wn * 32;
     GruBwdPf<4> f;
@@ -359,13 +363,17 @@ __device__ __forceinline__ void nt64_body(const ppk::NtProblem& g, float* lds, c
             }
             __builtin_amdgcn_sched_barrier(0);      // keep the reads ahead: the scheduler would sink them to their use
 #pragma unroll
-            for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[c & 1][s], b[c & 1][s], acc, 0, 0, 0);
+            for (int s = 0; s < 4; ++s) {
+                if (s & 1) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[c & 1][s], b[c & 1][s], acc1, 0, 0, 0);
+                else acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[c & 1][s], b[c & 1][s], acc, 0, 0, 0);
+            }
         }
         cur = (cur + 1) & 3;
     }
 
     __syncthreads();                                 // every wave is done with the staging buffers
     float* t = lds + wave * EPI_TILE;
+    acc += acc1;
     tile_to_lds(t, acc, li, h);
     if constexpr (MODE != 0) epi_gru_bwd<4, 1, MODE == 2>(g, t, 0, 0, row0, col0, lane, f);
     else epi_store<4, 1>(g, t, 0, 0, row0, col0, 0, g.N, lane);
@@ -570,9 +578,11 @@ __device__ __forceinline__ void nt32_body(const ppk::NtProblem& g, float* lds, c
     for (int c = 0; c < 4; ++c) xo[c] = 4 * ((2 * c + h) ^ sw);
     const int arow = li * BK, brow = 32 * BK + li * BK;
 
-    f32x16 acc;
+    // two independent accumulator chains (even / odd k chunks), added once at the end: a lone wave on a SIMD
+    // cannot issue dependent 32x32x2 MFMAs back to back (1830 instead of 1024 cycles per K tile measured)
+    f32x16 acc, acc1;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    for (int r = 0; r < 16; ++r) { acc[r] = 0.f; acc1[r] = 0.f; }
 
     const int nk = arows > 0 ? g.K / BK : 0;
     const int nkw = (nk - wave + 3) >> 2;           // K tiles of this wave
@@ -597,13 +607,17 @@ __device__ __forceinline__ void nt32_body(const ppk::NtProblem& g, float* lds, c
             }
             __builtin_amdgcn_sched_barrier(0);      // keep the reads ahead: the scheduler would sink them to their use
 #pragma unroll
-            for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[c & 1][s], b[c & 1][s], acc, 0, 0, 0);
+            for (int s = 0; s < 4; ++s) {
+                if (s & 1) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[c & 1][s], b[c & 1][s], acc1, 0, 0, 0);
+                else acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[c & 1][s], b[c & 1][s], acc, 0, 0, 0);
+            }
         }
         // this wave's reads of the buffer have returned (the MFMAs consumed them): refill it
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         if (i + 2 < nkw) stage(i & 1);
     }
     __syncthreads();
+    acc += acc1;
     tile_to_lds(lds + wave * EPI_TILE, acc, li, h);
     __syncthreads();
     if constexpr (MODE != 0) epi_gru_bwd<1, 4, MODE == 2>(g, lds, EPI_TILE, wave, m0, n0, lane, f);
@@ -785,19 +799,24 @@ bool gemm_nt_fast_ok(int64_t K, const float* A, int64_t lda, const float* B, int
 // fills the tile map of a launch for (tile_m x tile_n) tiles; returns the grid size (0 = nothing to do)
 static unsigned nt_tile_map(NtBatch& nb, int count, int tile_m, int tile_n, bool gate_layout)
 {
-    long long total = 0;
+    long long slots = 0;
     nb.count = count;
-    for (int i = 0; i < count; ++i) {
-        const NtProblem& p = nb.p[i];
-        const long long ncols = gate_layout ? p.H : p.N;
-        const long long tn = cdiv(ncols, tile_n), tm = cdiv(p.M, tile_m);
-        nb.tn[i] = (int)(tn > 0 ? tn : 1);
-        nb.toff[i] = (int)total;
-        total += tn * tm;
+    for (int i = 0; i < NT_MAX_GROUP; ++i) {
+        long long tn = 1, tm = 0;
+        if (i < count) {
+            const NtProblem& p = nb.p[i];
+            tn = cdiv(gate_layout ? p.H : p.N, tile_n);
+            tm = cdiv(p.M, tile_m);
+            if (tn < 1) { tn = 1; tm = 0; }
+        }
+        nb.tn[i] = (int)tn;
+        nb.tiles[i] = (int)(tn * tm);
+        nb.cp[i] = (int)cdiv(tn * tm, 8);
+        nb.coff[i] = (int)slots;
+        slots += nb.cp[i];
     }
-    for (int i = count; i <= NT_MAX_GROUP; ++i) nb.toff[i] = (int)total;
-    nb.chunk = (int)cdiv(total, 8);
-    return (unsigned)(8 * cdiv(total, 8));
+    nb.coff[NT_MAX_GROUP] = (int)slots;
+    return (unsigned)(8 * slots);
 }
 
 int gemm_nt64(const NtProblem* ps, int count, hipStream_t stream)

@@ -216,21 +216,26 @@ int ppk_stackgru_seq_fwd(int64_t T, const int64_t* batch_sizes_host, int64_t B, 
     const size_t lds_stack = sizeof(float) * (size_t)(3 + W);
     const int64_t H3 = 3 * H;
 
-    // products of the hidden state entering a step that are needed one step later:
-    //   gh[l] = W_hh[l] h_l + b_hh[l]  and  csraw = [W_c ; W_s] h_{L-1} + b   (rows < M)
-    auto next_step_products = [&](const float* hlast, int64_t M) -> int {
-        const ppk::NtProblem ps[2] = {
-            nt_store(hlast, H, M, w_hh[L - 1], H, H3, H, gh[(size_t)L - 1], H3, b_hh[L - 1], 0.f, H),
-            nt_store(hlast, H, M, wcs, H, 3 + W, H, csraw, ldcs, bcs, 0.f, H)};
-        return ppk::gemm_nt64(ps, 2, stream);
+    // Products of the hidden state entering a step that are needed one step later:
+    //   csraw = [W_c ; W_s] h_{L-1} + b   feeds k_stack_fwd of the next step: a launch of its own (tiny);
+    //   gh[l] = W_hh[l] h_l + b_hh[l]     rides in a gate-layout launch that has matrix work to hide it in:
+    //     l <  L-1: with cell l+1 of the same step (which has just consumed h_l as its input);
+    //     l == L-1: with cell 0 of the NEXT step — that launch is a K = ks (64) product whose GRU epilogue
+    //               is memory-bound, so the K = H product of the top layer shares its CUs (L >= 2 only:
+    //               with one layer, cell 0 itself needs gh[0] and the product goes with the heads).
+    auto heads = [&](const float* hlast, int64_t M) -> int {
+        ppk::NtProblem ps[2] = {nt_store(hlast, H, M, wcs, H, 3 + W, H, csraw, ldcs, bcs, 0.f, H), ppk::NtProblem{}};
+        int n = 1;
+        if (L == 1) ps[n++] = nt_store(hlast, H, M, w_hh[0], H, H3, H, gh[0], H3, b_hh[0], 0.f, H);
+        return ppk::gemm_nt64(ps, n, stream);
     };
     // prologue: the same products of the initial hidden state
-    for (int64_t l = 0; l + 1 < L; ++l) {
+    for (int64_t l = 0; l < L && L > 1; ++l) {
         const ppk::NtProblem p = nt_store(h0 + l * B * H, H, B, w_hh[l], H, H3, H, gh[(size_t)l], H3, b_hh[l], 0.f, H);
         rc = ppk::gemm_ntF(&p, 1, stream);
         if (rc) return rc;
     }
-    rc = next_step_products(h0 + (L - 1) * B * H, B);
+    rc = heads(h0 + (L - 1) * B * H, B);
     if (rc) return rc;
 
     for (int64_t t = 0; t < T; ++t) {
@@ -254,11 +259,14 @@ int ppk_stackgru_seq_fwd(int64_t T, const int64_t* batch_sizes_host, int64_t B, 
             // the layer below has just produced h_{l-1,t}: its recurrent product for step t+1 shares this launch
             if (l > 0 && Bn > 0)
                 ps[n++] = nt_store(Hs + ((l - 1) * NT + o) * H, H, Bn, w_hh[l - 1], H, H3, H, gh[(size_t)l - 1], H3, b_hh[l - 1], 0.f, H);
+            // the top layer's recurrent product of the PREVIOUS step (rows of this step) shares cell 0's launch
+            if (l == 0 && L > 1 && t > 0)
+                ps[n++] = nt_store(Hs + ((L - 1) * NT + op) * H, H, Bt, w_hh[L - 1], H, H3, H, gh[(size_t)L - 1], H3, b_hh[L - 1], 0.f, H);
             rc = ppk::gemm_ntF(ps, n, stream);
             if (rc) return rc;
         }
         if (Bn > 0) {
-            rc = next_step_products(Hs + ((L - 1) * NT + o) * H, Bn);
+            rc = heads(Hs + ((L - 1) * NT + o) * H, Bn);
             if (rc) return rc;
         }
     }

@@ -33,9 +33,9 @@ __global__ __launch_bounds__(256) void k_rows(const float* __restrict__ src, lon
 
 // ---- column sums: out[c] = sum_r A[r, c] ; two passes, fixed order ----------
 // pass 1: a block sums CS_CHUNK rows of 256 columns, 8 independent row streams per thread
-// (HBM-bound read of A); pass 2: 64 columns per block, 4 slices of the partials per column
-// summed in double and combined in a fixed order.
-constexpr int CS_CHUNK = 128;   // rows per partial
+// (HBM-bound read of A); pass 2: 32 columns per block, 8 slices of the partials per column, 8 loads
+// in flight per thread, summed in double and combined in a fixed order.
+constexpr int CS_CHUNK = 512;   // rows per partial
 __global__ __launch_bounds__(256) void k_colsum_part(const float* __restrict__ A, long long lda, long long R, int C,
                                                      float* __restrict__ part)
 {
@@ -54,18 +54,29 @@ __global__ __launch_bounds__(256) void k_colsum_part(const float* __restrict__ A
 __global__ __launch_bounds__(256) void k_colsum_final(const float* __restrict__ part, int nparts, int C, float beta,
                                                       float* __restrict__ out)
 {
-    __shared__ double red[4][64];
-    const int cl = threadIdx.x & 63, sl = threadIdx.x >> 6;
-    const int c = blockIdx.x * 64 + cl;
-    const int per = (nparts + 3) / 4;
+    __shared__ double red[8][32];
+    const int cl = threadIdx.x & 31, sl = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + cl;
+    const int per = (nparts + 7) / 8;
     const int p0 = sl * per, p1 = p0 + per < nparts ? p0 + per : nparts;
     double acc = 0.0;
-    if (c < C)
-        for (int p = p0; p < p1; ++p) acc += (double)part[(long long)p * C + c];
+    if (c < C) {
+        int p = p0;
+        for (; p + 8 <= p1; p += 8) {
+            float v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = part[(long long)(p + k) * C + c];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) acc += (double)v[k];
+        }
+        for (; p < p1; ++p) acc += (double)part[(long long)p * C + c];
+    }
     red[sl][cl] = acc;
     __syncthreads();
     if (sl == 0 && c < C) {
-        const double t = (red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl]);
+        double t = red[0][cl];
+#pragma unroll
+        for (int k = 1; k < 8; ++k) t += red[k][cl];
         out[c] = (beta != 0.f ? beta * out[c] : 0.f) + (float)t;
     }
 }
@@ -331,7 +342,7 @@ int ppk_colsum(const float* A, int64_t lda, int64_t rows, int64_t cols, float be
     dim3 grid((unsigned)((cols + 255) / 256), (unsigned)nparts);
     k_colsum_part<<<grid, dim3(256), 0, stream>>>(A, lda, rows, (int)cols, (float*)workspace);
     PPK_CHECK_LAUNCH("k_colsum_part");
-    k_colsum_final<<<dim3((unsigned)((cols + 63) / 64)), dim3(256), 0, stream>>>((const float*)workspace, nparts, (int)cols, beta, out);
+    k_colsum_final<<<dim3((unsigned)((cols + 31) / 32)), dim3(256), 0, stream>>>((const float*)workspace, nparts, (int)cols, beta, out);
     PPK_CHECK_LAUNCH("k_colsum_final");
     return PPK_OK;
 }

@@ -36,43 +36,68 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 
-// one block per active row: stack update (Appendix B) + stack top into X
+// row image <-> global: 16-byte accesses when the row (D*W floats) keeps 16-byte alignment, else scalar
+__device__ __forceinline__ void row_to_lds(float* dst, const float* src, int n, bool vec)
+{
+    if (vec) {
+        for (int j = threadIdx.x; j < (n >> 2); j += 256) reinterpret_cast<f32x4*>(dst)[j] = reinterpret_cast<const f32x4*>(src)[j];
+    } else {
+        for (int i = threadIdx.x; i < n; i += 256) dst[i] = src[i];
+    }
+}
+
+// one block per active row: stack update (Appendix B) + stack top into X.
+// The previous stack row is staged in LDS once (the update reads every element three times: as
+// itself, as the element above and as the element below) and the new row leaves as 16-byte stores.
 __global__ __launch_bounds__(256) void k_stack_fwd(const float* __restrict__ csraw, long long ldcs,
                                                    const float* __restrict__ Sprev,   // null at t == 0
                                                    float* __restrict__ Snew, float* __restrict__ CS,
                                                    float* __restrict__ Xtop, long long ldx, int D, int W)
 {
-    extern __shared__ float sm[];      // [0..2] controls, [3..3+W) s_in
+    extern __shared__ __align__(16) float sm[];      // previous row [D*W] (padded to 4), then [0..2] controls, [3..3+W) s_in
     const long long b = blockIdx.x;
+    const int DW = D * W, DW4 = (DW + 3) & ~3;
+    const bool vec = (DW & 3) == 0;
+    float* spl = sm;
+    float* act = sm + DW4;
     const float* raw = csraw + b * ldcs;
     if (threadIdx.x == 0) {
         float p0 = raw[0], p1 = raw[1], p2 = raw[2];
         float m = fmaxf(p0, fmaxf(p1, p2));
         float e0 = expf(p0 - m), e1 = expf(p1 - m), e2 = expf(p2 - m);
         float inv = 1.0f / (e0 + e1 + e2);
-        sm[0] = e0 * inv; sm[1] = e1 * inv; sm[2] = e2 * inv;
+        act[0] = e0 * inv; act[1] = e1 * inv; act[2] = e2 * inv;
     }
-    for (int w = threadIdx.x; w < W; w += 256) sm[3 + w] = tanhf(raw[3 + w]);
+    for (int w = threadIdx.x; w < W; w += 256) act[3 + w] = tanhf(raw[3 + w]);
+    const long long base = b * (long long)DW;
+    if (Sprev) row_to_lds(spl, Sprev + base, DW, vec);
+    else for (int i = threadIdx.x; i < DW; i += 256) spl[i] = 0.f;
     __syncthreads();
-    const float a_push = sm[0], a_pop = sm[1], a_noop = sm[2];
+    const float a_push = act[0], a_pop = act[1], a_noop = act[2];
     float* cs = CS + b * ldcs;
-    for (int i = threadIdx.x; i < 3 + W; i += 256) cs[i] = sm[i];
-    const long long base = b * (long long)D * W;
-    const float* sp = Sprev ? Sprev + base : nullptr;
+    for (int i = threadIdx.x; i < 3 + W; i += 256) cs[i] = act[i];
     float* sn = Snew + base;
-    for (int i = threadIdx.x; i < D * W; i += 256) {
+    auto upd = [&](int i) {
         const int d = i / W, w = i - d * W;
-        float cur = 0.f, up, down = 0.f;
-        if (sp) {
-            cur = sp[i];
-            up = d == 0 ? sm[3 + w] : sp[i - W];
-            if (d < D - 1) down = sp[i + W];
-        } else {
-            up = d == 0 ? sm[3 + w] : 0.f;
+        const float up = d == 0 ? act[3 + w] : spl[i - W];
+        const float down = d < D - 1 ? spl[i + W] : 0.f;
+        return a_noop * spl[i] + a_push * up + a_pop * down;
+    };
+    if (vec) {
+        for (int j = threadIdx.x; j < (DW >> 2); j += 256) {
+            f32x4 v;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] = upd(4 * j + k);
+            reinterpret_cast<f32x4*>(sn)[j] = v;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) if (4 * j + k < W) Xtop[b * ldx + 4 * j + k] = v[k];
         }
-        const float v = a_noop * cur + a_push * up + a_pop * down;
-        sn[i] = v;
-        if (d == 0) Xtop[b * ldx + w] = v;
+    } else {
+        for (int i = threadIdx.x; i < DW; i += 256) {
+            const float v = upd(i);
+            sn[i] = v;
+            if (i < W) Xtop[b * ldx + i] = v;
+        }
     }
     for (int w = W + threadIdx.x; w < ldx; w += 256) Xtop[b * ldx + w] = 0.f;      // zero padding of the K operand
 }
@@ -86,50 +111,56 @@ __device__ __forceinline__ float block_sum_256(float v, float* red)
     return (red[0] + red[1]) + (red[2] + red[3]);
 }
 
-// backward of the stack update for one step; one block per active row.
+// backward of the stack update for one step; one block per active row.  Both row images (the incoming
+// stack gradient and the previous stack) are staged in LDS with 16-byte loads.
 __global__ __launch_bounds__(256) void k_stack_bwd(const float* __restrict__ dS_in,   // [B, D, W] carry (zeros where none)
                                                    const float* __restrict__ dXtop, long long ldx,
                                                    const float* __restrict__ Sprev,   // null at t == 0
                                                    const float* __restrict__ CS, long long ldcs,
                                                    float* __restrict__ DCS, float* __restrict__ dS_out, int D, int W)
 {
-    extern __shared__ float sm[];      // dS_t row image [D*W] + 3 + W activations
+    extern __shared__ __align__(16) float sm[];      // dS_t row image [D*W] (padded to 4), previous stack row [D*W] (padded), 3 + W activations
     __shared__ float red[4];
     const long long b = blockIdx.x;
-    const int DW = D * W;
+    const int DW = D * W, DW4 = (DW + 3) & ~3;
+    const bool vec = (DW & 3) == 0;
     float* dst = sm;
-    float* act = sm + DW;
+    float* spl = sm + DW4;
+    float* act = sm + 2 * DW4;
     const float* cs = CS + b * ldcs;
     for (int i = threadIdx.x; i < 3 + W; i += 256) act[i] = cs[i];
     const long long base = b * (long long)DW;
-    for (int i = threadIdx.x; i < DW; i += 256) {
-        float v = dS_in[base + i];
-        if (i < W) v += dXtop[b * ldx + i];
-        dst[i] = v;
-    }
+    row_to_lds(dst, dS_in + base, DW, vec);
+    if (Sprev) row_to_lds(spl, Sprev + base, DW, vec);
+    else for (int i = threadIdx.x; i < DW; i += 256) spl[i] = 0.f;
+    __syncthreads();
+    for (int i = threadIdx.x; i < W; i += 256) dst[i] += dXtop[b * ldx + i];
     __syncthreads();
     const float a_push = act[0], a_pop = act[1], a_noop = act[2];
-    const float* sp = Sprev ? Sprev + base : nullptr;
     float s_noop = 0.f, s_push = 0.f, s_pop = 0.f;
-    for (int i = threadIdx.x; i < DW; i += 256) {
+    auto elem = [&](int i) {
         const int d = i / W, w = i - d * W;
         const float g = dst[i];
-        float cur = 0.f, up, down = 0.f;
-        if (sp) {
-            cur = sp[i];
-            up = d == 0 ? act[3 + w] : sp[i - W];
-            if (d < D - 1) down = sp[i + W];
-        } else {
-            up = d == 0 ? act[3 + w] : 0.f;
-        }
-        s_noop = fmaf(g, cur, s_noop);
+        const float up = d == 0 ? act[3 + w] : spl[i - W];
+        const float down = d < D - 1 ? spl[i + W] : 0.f;
+        s_noop = fmaf(g, spl[i], s_noop);
         s_push = fmaf(g, up, s_push);
         s_pop = fmaf(g, down, s_pop);
         // gradient wrt the previous stack
         float o = a_noop * g;
         if (d + 1 < D) o = fmaf(a_push, dst[i + W], o);
         if (d >= 1) o = fmaf(a_pop, dst[i - W], o);
-        dS_out[base + i] = o;
+        return o;
+    };
+    if (vec) {
+        for (int j = threadIdx.x; j < (DW >> 2); j += 256) {
+            f32x4 o;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) o[k] = elem(4 * j + k);
+            reinterpret_cast<f32x4*>(dS_out + base)[j] = o;
+        }
+    } else {
+        for (int i = threadIdx.x; i < DW; i += 256) dS_out[base + i] = elem(i);
     }
     s_noop = block_sum_256(s_noop, red);
     s_push = block_sum_256(s_push, red);
@@ -157,7 +188,7 @@ int check_dims(const SeqDims& d, const int64_t* bs, std::vector<int64_t>& off)
     if (d.H % 32) PPK_FAIL(PPK_ERR_UNSUP, "stackgru: rnn_cell_size must be a multiple of 32 (the host side pads with zero units)");
     if (d.ks < d.W || d.ks % 32 || d.ldcs < 3 + d.W || d.ldcs % 32)
         PPK_FAIL(PPK_ERR_ALIGN, "stackgru: ks / ldcs must cover W / 3+W and be multiples of 32");
-    if ((size_t)(d.D * d.W + 3 + d.W) * 4 > 60 * 1024) PPK_FAIL(PPK_ERR_UNSUP, "stackgru: stack_depth*stack_width too large for LDS");
+    if ((size_t)(2 * (d.D * d.W + 4) + 3 + d.W) * 4 > 60 * 1024) PPK_FAIL(PPK_ERR_UNSUP, "stackgru: stack_depth*stack_width too large for LDS");
     if (!bs) PPK_FAIL(PPK_ERR_NULL, "stackgru: batch_sizes is null");
     off.assign((size_t)d.T + 1, 0);
     for (int64_t t = 0; t < d.T; ++t) {
@@ -213,7 +244,7 @@ int ppk_stackgru_seq_fwd(int64_t T, const int64_t* batch_sizes_host, int64_t B, 
     std::vector<float*> gh((size_t)L);
     for (int64_t l = 0; l < L; ++l) gh[(size_t)l] = (float*)ppk_carve(cur, sizeof(float) * (size_t)B * 3 * H);
     float* csraw = (float*)ppk_carve(cur, sizeof(float) * (size_t)B * ldcs);
-    const size_t lds_stack = sizeof(float) * (size_t)(3 + W);
+    const size_t lds_stack = sizeof(float) * (size_t)(((D * W + 3) & ~(int64_t)3) + 3 + W);
     const int64_t H3 = 3 * H;
 
     // Products of the hidden state entering a step that are needed one step later:
@@ -308,7 +339,7 @@ int ppk_stackgru_seq_bwd(int64_t T, const int64_t* batch_sizes_host, int64_t B, 
     PPK_HIP(hipMemsetAsync(dSa, 0, sbytes, stream));
     PPK_HIP(hipMemsetAsync(dSb, 0, sbytes, stream));
     PPK_HIP(hipMemsetAsync(dh0, 0, sizeof(float) * (size_t)L * B * H, stream));
-    const size_t lds_stack = sizeof(float) * (size_t)(D * W + 3 + W);
+    const size_t lds_stack = sizeof(float) * (size_t)(2 * ((D * W + 3) & ~(int64_t)3) + 3 + W);
     const int64_t H3 = 3 * H;
 
     auto gru_bwd_problem = [&](const float* A, int64_t lda, int64_t a_rows, const float* Bm, int64_t ldb, int64_t K,

@@ -246,6 +246,129 @@ __global__ __launch_bounds__(256) void k_gemm(const GemmBatch gb)
         }
 }
 
+// ---------------------------------------------------------------------------
+// k_tn128: C = A^T . B with BOTH operands x-contiguous (A [K, M], B [K, N]) — the long-K weight
+// gradients  dW = dG^T . X  over all tokens of the batch.  No transposition anywhere: rows of k are
+// staged by LDS-DMA (global_load_lds_dwordx4, two 512-byte k rows per wave instruction) into a
+// [k][128] image, double buffered, one raw barrier per K tile; an MFMA operand (row m = lane & 31,
+// k = 2 s + (lane >> 5)) is one ds_read_b32 with consecutive lanes on consecutive dwords.  Odd k
+// rows are stored with their 16-byte chunks XOR 8 (applied to the DMA source address) so the two
+// half-waves of a read hit disjoint banks.  128 x 128 tile, 4 waves 2 x 2, four 32 x 32 accumulators
+// per wave (64 MFMAs per wave between barriers keep the matrix pipe queued across them).
+// Needs M % 4 == 0, N % 4 == 0, 16-byte aligned operands; slabs start at multiples of 32; the K tail
+// (< 32 rows of the last slab) is multiplied straight from global memory with zero-filled lanes.
+// ---------------------------------------------------------------------------
+#define PPK_LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
+constexpr int TN_BUF = 2 * BK * 128;           // floats per stage (A image + B image)
+
+__global__ __launch_bounds__(256) void k_tn128(const GemmArgs g)
+{
+    __shared__ __align__(1024) float lds[2 * TN_BUF];
+    const int m0 = blockIdx.y * 128, n0 = blockIdx.x * 128;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1, li = lane & 31, h = lane >> 5;
+    const int kbeg = blockIdx.z * g.kslice;
+    const int kend = min(g.K, kbeg + g.kslice);
+    const int nk = (kend - kbeg) / BK;
+
+    // DMA piece q = wave + 4 p (p = 0..3) covers k rows 2 q, 2 q + 1 of the tile; lane -> row 2 q + h, physical chunk li
+    const int lchunk = li ^ (8 * h);                                  // logical 16-byte chunk held by this lane's slot
+    int ca = m0 + 4 * lchunk; ca = ca < g.M - 4 ? ca : g.M - 4;       // clamped columns (their outputs are never stored)
+    int cb = n0 + 4 * lchunk; cb = cb < g.N - 4 ? cb : g.N - 4;
+    const float* ga = g.A + (long long)(kbeg + 2 * wave + h) * g.lda + ca;
+    const float* gbp = g.B + (long long)(kbeg + 2 * wave + h) * g.ldb + cb;
+    const long long sa = 8 * g.lda, sb = 8 * g.ldb;                    // piece p -> + 8 k rows
+    auto stage = [&](int buf) {
+        float* la = lds + buf * TN_BUF;
+        float* lb = la + BK * 128;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) __builtin_amdgcn_global_load_lds(ga + p * sa, PPK_LDS_PTR(la + (wave + 4 * p) * 256), 16, 0, 0);
+#pragma unroll
+        for (int p = 0; p < 4; ++p) __builtin_amdgcn_global_load_lds(gbp + p * sb, PPK_LDS_PTR(lb + (wave + 4 * p) * 256), 16, 0, 0);
+        ga += (long long)BK * g.lda;
+        gbp += (long long)BK * g.ldb;
+    };
+    // fragment element (k = 2 s + h, m): float offset k * 128 + 4 * ((m >> 2) ^ 8 h) + (m & 3)
+    int offa[2], offb[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int ma = wm * 64 + i * 32 + li, mb = wn * 64 + i * 32 + li;
+        offa[i] = h * 128 + 4 * ((ma >> 2) ^ (8 * h)) + (ma & 3);
+        offb[i] = BK * 128 + h * 128 + 4 * ((mb >> 2) ^ (8 * h)) + (mb & 3);
+    }
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    if (nk > 0) stage(0);
+    int cur = 0;
+    for (int it = 0; it < nk; ++it) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (it + 1 < nk) stage(cur ^ 1);
+        const float* base = lds + cur * TN_BUF;
+#pragma unroll
+        for (int s = 0; s < BK / 2; ++s) {
+            float a[2], b[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) { a[i] = base[offa[i] + s * 256]; b[i] = base[offb[i] + s * 256]; }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        cur ^= 1;
+    }
+    // K tail: fewer than 32 rows, straight from global memory (lanes beyond the end contribute zeros)
+    for (int k = kbeg + nk * BK; k < kend; k += 2) {
+        const int kk = k + h;
+        const bool ok = kk < kend;
+        const int kr = ok ? kk : kend - 1;
+        float a[2], b[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            int ma = m0 + wm * 64 + i * 32 + li; ma = ma < g.M ? ma : g.M - 1;
+            int mb = n0 + wn * 64 + i * 32 + li; mb = mb < g.N ? mb : g.N - 1;
+            const float va = g.A[(long long)kr * g.lda + ma], vb = g.B[(long long)kr * g.ldb + mb];
+            a[i] = ok ? va : 0.f;
+            b[i] = ok ? vb : 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+
+    const bool slab = g.ksplit > 1;
+    float* Cout = slab ? g.slabs + (long long)blockIdx.z * g.M * g.N : g.C;
+    const long long ldo = slab ? g.N : g.ldc;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = n0 + wn * 64 + j * 32 + li;
+            if (col >= g.N) continue;
+            const float bv = (!slab && g.bias) ? g.bias[col] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (row >= g.M) continue;
+                float* p = Cout + (long long)row * ldo + col;
+                float v = acc[i][j][r];
+                if (!slab) {
+                    v = g.alpha * v + bv;
+                    if (g.beta != 0.f) v = fmaf(g.beta, *p, v);
+                }
+                *p = v;
+            }
+        }
+}
+
 // sums the K slabs in slice order, then applies alpha / beta / bias.
 __global__ __launch_bounds__(256) void k_gemm_reduce(const GemmArgs g)
 {
@@ -300,7 +423,9 @@ Plan make_plan(long long M, long long N, long long K, bool allow_split)
     else pl.tile = 0;
     const long long blocks = pl.tile == 2 ? b22 : (pl.tile == 1 ? b21 : b11);
     if (allow_split && blocks < 256 && K >= 2048) {
-        long long want = cdiv(768, blocks);                 // three resident blocks per CU
+        long long target = 768;                             // three resident blocks per CU
+        if (const char* e = getenv("PPK_GEMM_WGS")) target = atoll(e);
+        long long want = target / blocks > 0 ? target / blocks : 1;
         long long maxs = K / 1024;
         long long s = want < maxs ? want : maxs;
         if (s > 64) s = 64;
@@ -384,8 +509,17 @@ int gemm(int transA, int transB, int64_t M, int64_t N, int64_t K, float alpha,
             g.slabs = (float*)ws;
         }
     }
-    dispatch(gb, 1, pl.tile, a_kc, b_kc, 2.0 * (double)M * (double)N * (double)K, stream);
-    PPK_CHECK_LAUNCH("k_gemm");
+    const char* tn_env = getenv("PPK_GEMM_TN");                       // tuning aid: 0 keeps the register-staged kernel
+    const bool tn_fast = !a_kc && !b_kc && pl.tile == 2 && g.a_vec && g.b_vec && !(M & 3) && !(N & 3) && M >= 4 && N >= 4 &&
+                         !(tn_env && atoi(tn_env) == 0);
+    if (tn_fast) {
+        ppk::ProfScope prof(PK_GEMM_TN128, 2.0 * (double)M * (double)N * (double)K, stream);
+        k_tn128<<<dim3((unsigned)cdiv(N, 128), (unsigned)cdiv(M, 128), (unsigned)g.ksplit), dim3(256), 0, stream>>>(g);
+        PPK_CHECK_LAUNCH("k_tn128");
+    } else {
+        dispatch(gb, 1, pl.tile, a_kc, b_kc, 2.0 * (double)M * (double)N * (double)K, stream);
+        PPK_CHECK_LAUNCH("k_gemm");
+    }
     if (g.ksplit > 1) {
         long long total = (long long)M * N;
         unsigned nb = (unsigned)(cdiv(total, 256) < 2048 ? cdiv(total, 256) : 2048);

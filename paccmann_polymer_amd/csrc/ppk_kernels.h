@@ -56,7 +56,7 @@ enum ProfKind {
     PK_GEMM_L_XX, PK_GEMM_L_XK, PK_GEMM_L_KX, PK_GEMM_L_KK,          // 128x128 tiles
     PK_STACK_FWD, PK_STACK_BWD, PK_GATE_FWD, PK_GATE_BWD,
     PK_GRAPHREG_TERMS, PK_GRAPHREG_DZ, PK_SPMM, PK_GRAPHREG_SPARSE,
-    PK_GEMM_NT64, PK_GEMM_NTF, PK_GEMM_NT32, PK_GEMM_NTFS,
+    PK_GEMM_NT64, PK_GEMM_NTF, PK_GEMM_NT32, PK_GEMM_NTFS, PK_GEMM_TN128,
     PK_COUNT
 };
 struct ProfScope {

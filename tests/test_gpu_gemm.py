@@ -9,6 +9,8 @@ SHAPES = [
     # M, N, K
     (128, 128, 32), (64, 64, 8), (1, 1, 1), (37, 53, 178), (2048, 1536, 512), (300, 1536, 178),
     (2048, 53, 512), (77, 690, 1536), (1536, 512, 5000), (53, 512, 3001), (130, 200, 4),
+    # long K, N > 192: the TN layout takes the LDS-DMA kernel k_tn128 (split-K slabs, odd K tail, partial tiles)
+    (384, 256, 9001), (200, 196, 8200), (1536, 512, 20011),
 ]
 
 

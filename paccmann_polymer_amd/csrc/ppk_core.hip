@@ -46,7 +46,7 @@ std::vector<ProfRec> g_prof;
 const char* const kKindNames[ppk::PK_COUNT] = {
     "k_gemm<64,64,XX>", "k_gemm<64,64,XK>", "k_gemm<64,64,KX>", "k_gemm<64,64,KK>",
     "k_gemm<128,128,XX>", "k_gemm<128,128,XK>", "k_gemm<128,128,KX>", "k_gemm<128,128,KK>",
-    "k_stack_fwd", "k_stack_bwd", "k_gate_fwd", "k_gate_bwd",
+    "k_stack_fwd", "k_stack_bwd",
     "k_terms", "k_dz", "k_spmm", "k_graphreg_sparse",
     "k_nt64", "k_ntF", "k_nt32", "k_ntFs", "k_tn128",
 };

@@ -150,10 +150,7 @@ struct GemmArgs {
     float* slabs;        // [ksplit][M][N] when ksplit > 1
     int a_vec, b_vec;    // operand base 16-B aligned and leading dimension % 4 == 0 -> float4 loads
 };
-// up to MAX_GROUP independent problems per launch (grid.z picks the problem): the
-// hidden-side gate GEMMs of all GRU layers of a step share one launch so the grid fills the chip.
-constexpr int MAX_GROUP = 4;
-struct GemmBatch { GemmArgs p[MAX_GROUP]; int grouped; };
+struct GemmBatch { GemmArgs p[1]; };
 
 template <int BM, int BN, bool A_KC, bool B_KC>
 __global__ __launch_bounds__(256) void k_gemm(const GemmBatch gb)
@@ -163,13 +160,12 @@ __global__ __launch_bounds__(256) void k_gemm(const GemmBatch gb)
     float* ldsA = lds;
     float* ldsB = lds + lds_floats<BM, A_KC>();
 
-    const GemmArgs& g = gb.p[gb.grouped ? blockIdx.z : 0];
+    const GemmArgs& g = gb.p[0];
     const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
-    if (m0 >= g.M || n0 >= g.N) return;             // grouped launch: grid is the max over problems
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int li = lane & 31, h = lane >> 5;
-    const int kbeg = gb.grouped ? 0 : blockIdx.z * g.kslice;
+    const int kbeg = blockIdx.z * g.kslice;
     const int kend = min(g.K, kbeg + g.kslice);
 
     f32x16 acc[TM][TN];
@@ -394,7 +390,7 @@ void launch(const GemmBatch& gb, int count, bool a_kc, bool b_kc, hipStream_t st
         gx = gx > cdiv(gb.p[i].N, BN) ? gx : cdiv(gb.p[i].N, BN);
         gy = gy > cdiv(gb.p[i].M, BM) ? gy : cdiv(gb.p[i].M, BM);
     }
-    dim3 grid((unsigned)gx, (unsigned)gy, gb.grouped ? count : gb.p[0].ksplit), block(256);
+    dim3 grid((unsigned)gx, (unsigned)gy, gb.p[0].ksplit), block(256);
     if (a_kc && b_kc)        k_gemm<BM, BN, true, true><<<grid, block, 0, stream>>>(gb);
     else if (a_kc && !b_kc)  k_gemm<BM, BN, true, false><<<grid, block, 0, stream>>>(gb);
     else if (!a_kc && b_kc)  k_gemm<BM, BN, false, true><<<grid, block, 0, stream>>>(gb);
@@ -488,7 +484,6 @@ int gemm(int transA, int transB, int64_t M, int64_t N, int64_t K, float alpha,
     if (rc) return rc;
     const bool a_kc = !transA, b_kc = transB != 0;
     GemmBatch gb;
-    gb.grouped = 0;
     GemmArgs& g = gb.p[0];
     fill_args(g, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, bias);
     Plan pl = make_plan(M, N, K, ws != nullptr);
@@ -527,32 +522,6 @@ int gemm(int transA, int transB, int64_t M, int64_t N, int64_t K, float alpha,
         PPK_CHECK_LAUNCH("k_gemm_reduce");
     }
     return PPK_OK;
-}
-
-// Up to MAX_GROUP independent NT problems (C_i = alpha_i A_i B_i^T + beta_i C_i + bias_i) in ONE launch.
-int gemm_nt_group(const GemmProblem* ps, int count, hipStream_t stream)
-{
-    if (count < 1 || count > MAX_GROUP) PPK_FAIL(PPK_ERR_UNSUP, "gemm_nt_group: 1..%d problems", MAX_GROUP);
-    GemmBatch gb;
-    gb.grouped = 1;
-    double flops = 0;
-    for (int i = 0; i < count; ++i) {
-        const GemmProblem& p = ps[i];
-        if (p.M == 0 || p.N == 0) PPK_FAIL(PPK_ERR_SHAPE, "gemm_nt_group: empty problem");
-        int rc = check_problem(0, 1, p.M, p.N, p.K, p.A, p.lda, p.B, p.ldb, p.C, p.ldc);
-        if (rc) return rc;
-        fill_args(gb.p[i], p.M, p.N, p.K, p.alpha, p.A, p.lda, p.B, p.ldb, p.beta, p.C, p.ldc, p.bias);
-        flops += 2.0 * (double)p.M * (double)p.N * (double)p.K;
-    }
-    dispatch(gb, count, 0, true, true, flops, stream);
-    PPK_CHECK_LAUNCH("k_gemm(group)");
-    return PPK_OK;
-}
-
-int gemm_nt_pair(const GemmProblem& p0, const GemmProblem& p1, hipStream_t stream)
-{
-    const GemmProblem ps[2] = {p0, p1};
-    return gemm_nt_group(ps, 2, stream);
 }
 
 }  // namespace ppk

@@ -328,11 +328,9 @@ __device__ __forceinline__ void nt64_body(const ppk::NtProblem& g, float* lds, c
     const int arow = (wm * 32 + li) * BK;
     const int brow = BM * BK + (wn * 32 + li) * BK;
 
-    // two independent accumulator chains (even / odd k chunks), added once at the end: a lone wave on a SIMD
-    // cannot issue dependent 32x32x2 MFMAs back to back (1830 instead of 1024 cycles per K tile measured)
-    f32x16 acc, acc1;
+    f32x16 acc;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { acc[r] = 0.f; acc1[r] = 0.f; }
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 
     const int row0 = m0 + wm * 32, col0 = n0 + wn * 32;
     GruBwdPf<4> f;
@@ -363,17 +361,13 @@ __device__ __forceinline__ void nt64_body(const ppk::NtProblem& g, float* lds, c
             }
             __builtin_amdgcn_sched_barrier(0);      // keep the reads ahead: the scheduler would sink them to their use
 #pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                if (s & 1) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[c & 1][s], b[c & 1][s], acc1, 0, 0, 0);
-                else acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[c & 1][s], b[c & 1][s], acc, 0, 0, 0);
-            }
+            for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[c & 1][s], b[c & 1][s], acc, 0, 0, 0);
         }
         cur = (cur + 1) & 3;
     }
 
     __syncthreads();                                 // every wave is done with the staging buffers
     float* t = lds + wave * EPI_TILE;
-    acc += acc1;
     tile_to_lds(t, acc, li, h);
     if constexpr (MODE != 0) epi_gru_bwd<4, 1, MODE == 2>(g, t, 0, 0, row0, col0, lane, f);
     else epi_store<4, 1>(g, t, 0, 0, row0, col0, 0, g.N, lane);
@@ -578,11 +572,9 @@ __device__ __forceinline__ void nt32_body(const ppk::NtProblem& g, float* lds, c
     for (int c = 0; c < 4; ++c) xo[c] = 4 * ((2 * c + h) ^ sw);
     const int arow = li * BK, brow = 32 * BK + li * BK;
 
-    // two independent accumulator chains (even / odd k chunks), added once at the end: a lone wave on a SIMD
-    // cannot issue dependent 32x32x2 MFMAs back to back (1830 instead of 1024 cycles per K tile measured)
-    f32x16 acc, acc1;
+    f32x16 acc;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { acc[r] = 0.f; acc1[r] = 0.f; }
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 
     const int nk = arows > 0 ? g.K / BK : 0;
     const int nkw = (nk - wave + 3) >> 2;           // K tiles of this wave
@@ -607,17 +599,13 @@ __device__ __forceinline__ void nt32_body(const ppk::NtProblem& g, float* lds, c
             }
             __builtin_amdgcn_sched_barrier(0);      // keep the reads ahead: the scheduler would sink them to their use
 #pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                if (s & 1) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[c & 1][s], b[c & 1][s], acc1, 0, 0, 0);
-                else acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[c & 1][s], b[c & 1][s], acc, 0, 0, 0);
-            }
+            for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[c & 1][s], b[c & 1][s], acc, 0, 0, 0);
         }
         // this wave's reads of the buffer have returned (the MFMAs consumed them): refill it
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         if (i + 2 < nkw) stage(i & 1);
     }
     __syncthreads();
-    acc += acc1;
     tile_to_lds(lds + wave * EPI_TILE, acc, li, h);
     __syncthreads();
     if constexpr (MODE != 0) epi_gru_bwd<1, 4, MODE == 2>(g, lds, EPI_TILE, wave, m0, n0, lane, f);
@@ -768,6 +756,15 @@ bool use_small_64(long long tiles64, double tileK64, double tileK32, long long t
     const double t32 = 4.0 + 1e-3 * (2.9 * (double)tiles32 + 0.0181 * tileK32);
     return t32 < t64;
 }
+// env PPK_NT_FAMILY = 32 / 64 forces a family (tools/bench_nt_families.py).  A 128 x 64 tile with two accumulators
+// per wave (k_nt128) was built and measured: 57 us for one 128 x 64 x 1536 tile per CU against 38 us for the
+// 64 x 64 tile and 58.9 us for two of them — never faster, removed.
+int pick_family(int fam)
+{
+    static int forced = -1;
+    if (forced < 0) { const char* e = getenv("PPK_NT_FAMILY"); forced = e ? atoi(e) : 0; }
+    return (forced == 32 || forced == 64) ? forced : fam;
+}
 bool use_small_F(long long tilesF)
 {
     if (g_small_limit_f == -2) { const char* e = getenv("PPK_NTF_SMALL"); g_small_limit_f = e ? atoll(e) : -1; }
@@ -849,7 +846,9 @@ int gemm_nt64(const NtProblem* ps, int count, hipStream_t stream)
     }
     if (tiles64 == 0) return PPK_OK;
     if (tiles64 > 0x0fffffff) PPK_FAIL(PPK_ERR_UNSUP, "gemm_nt64: too many tiles");
-    if (use_small_64(tiles64, tileK64, tileK32, tiles32)) {
+    int family = use_small_64(tiles64, tileK64, tileK32, tiles32) ? 32 : 64;
+    if (small_grid_limit() < 0) family = pick_family(family);
+    if (family == 32) {
         // 32 x 32 tiles with K split over the waves
         const unsigned grid = nt_tile_map(nb, count, 32, 32, false);
         ProfScope prof(PK_GEMM_NT32, flops, stream);

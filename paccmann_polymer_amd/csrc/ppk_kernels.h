@@ -14,17 +14,6 @@ int gemm(int transA, int transB, int64_t M, int64_t N, int64_t K, float alpha,
          float* C, int64_t ldc, const float* bias, void* ws, size_t ws_bytes, hipStream_t stream);
 size_t gemm_workspace_bytes(int64_t M, int64_t N, int64_t K);
 
-// C = alpha * A . B^T + beta * C + bias  (A [M,K], B [N,K], both k-contiguous)
-struct GemmProblem {
-    int64_t M, N, K;
-    float alpha; const float* A; int64_t lda; const float* B; int64_t ldb;
-    float beta; float* C; int64_t ldc; const float* bias;
-};
-// two independent NT problems in one launch (64x64 tiles, grid.z = problem)
-int gemm_nt_pair(const GemmProblem& p0, const GemmProblem& p1, hipStream_t stream);
-// up to 4 independent NT problems in one launch
-int gemm_nt_group(const GemmProblem* ps, int count, hipStream_t stream);
-
 // ---- NT GEMMs with LDS-DMA staging and fused GRU epilogues (ppk_gemm_nt.hip) ----
 //   acc[M,N] = A[M,K] . B[N,K]^T ; K % 32 == 0, lda/ldb % 4 == 0, 16-byte aligned operands.
 //   Only the first a_rows rows of A exist: rows >= a_rows contribute acc = 0 (their loads are clamped).
@@ -54,7 +43,7 @@ int gemm_ntF(const NtProblem* ps, int count, hipStream_t stream);    // 128 x (3
 enum ProfKind {
     PK_GEMM_S_XX = 0, PK_GEMM_S_XK, PK_GEMM_S_KX, PK_GEMM_S_KK,      // 64x64 tiles;  A,B layout: K = k-contiguous, X = x-contiguous
     PK_GEMM_L_XX, PK_GEMM_L_XK, PK_GEMM_L_KX, PK_GEMM_L_KK,          // 128x128 tiles
-    PK_STACK_FWD, PK_STACK_BWD, PK_GATE_FWD, PK_GATE_BWD,
+    PK_STACK_FWD, PK_STACK_BWD,
     PK_GRAPHREG_TERMS, PK_GRAPHREG_DZ, PK_SPMM, PK_GRAPHREG_SPARSE,
     PK_GEMM_NT64, PK_GEMM_NTF, PK_GEMM_NT32, PK_GEMM_NTFS, PK_GEMM_TN128,
     PK_COUNT

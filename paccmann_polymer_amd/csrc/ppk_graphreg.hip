@@ -73,25 +73,84 @@ __global__ __launch_bounds__(256) void k_dist(const float* __restrict__ z, long 
     if (lane == 0 && mx > 0.0f) atomicMax(&segM[s.seg], __float_as_uint(mx));   // D >= 0: uint order == float order
 }
 
-// graph_regularizer_function (:4-10): value and d/d(di); d/d(dj) = -that.
-__device__ __forceinline__ float reg_f(int sgn, float di, float dj, float& dfa)
+// graph_regularizer_function (:4-10) for delta = g1 - g2: value and d/d(di); d/d(dj) = -that.
+//   delta == 0 -> (di - dj)^2 ; delta > 0 -> relu(dj - di) ; delta < 0 -> relu(di - dj)
+// Written with selects only: the three-way branch cost ~40 instructions per evaluation with divergent
+// exec masks, this form ~16 (bitwise the same results; a NaN delta counts as 0 like before).
+template <typename GT>
+__device__ __forceinline__ float reg_f(GT g1, GT g2, float di, float dj, float& dfa)
 {
-    float t = di - dj;
-    if (sgn == 0) { dfa = 2.0f * t; return t * t; }
-    if (sgn > 0) {                      // relu(dj - di)
-        bool on = dj > di;
-        dfa = on ? -1.0f : 0.0f;
-        return on ? -t : 0.0f;
-    }
-    bool on = di > dj;                  // relu(di - dj)
-    dfa = on ? 1.0f : 0.0f;
-    return on ? t : 0.0f;
+    const bool gt = g1 > g2, lt = g1 < g2;
+    const float t = di - dj;
+    const bool on = (gt & (dj > di)) | (lt & (di > dj));
+    const bool eq = !(gt | lt);
+    dfa = eq ? 2.0f * t : (on ? (gt ? -1.0f : 1.0f) : 0.0f);
+    return eq ? t * t : (on ? (gt ? -t : t) : 0.0f);
 }
 
-template <typename GT>
-__device__ __forceinline__ int sgn_cmp(GT a, GT b) { return (a > b) - (a < b); }
-
 // ---------------------------------------------------------------- k_terms
+// The two rasters of one anchor a on LDS-resident columns; LT = type the G column / row is held in.
+// Returns this thread's share of the anchor's sum of f (fp64) and writes T[a][x].
+template <typename LT>
+__device__ __forceinline__ double terms_body(const LT* __restrict__ Gcol, const LT* __restrict__ Grow, const float* __restrict__ Da,
+                                             int n, int a, float* __restrict__ Trow)
+{
+    double S = 0.0;
+    for (int x = threadIdx.x; x < n; x += blockDim.x) {
+        float t = 0.0f;
+        const float dx = Da[x];
+        // ---- column raster, j = a (:49-57).  pairs (i, r): i < a, r >= i, r != a
+        const LT gcx = Gcol[x];
+        if (x < a) {                                   // x plays i
+            float A = 0.0f, Sx = 0.0f;
+#pragma unroll 4
+            for (int r = x; r < n; ++r) {
+                float dfa;
+                const float v = reg_f<LT>(gcx, Gcol[r], dx, Da[r], dfa);
+                Sx += r == a ? 0.0f : v;               // r != a (adding 0.0f to a non-negative sum changes nothing)
+                A += r == a ? 0.0f : dfa;
+            }
+            t += A;
+            S += (double)Sx;
+        }
+        if (x != a) {                                  // x plays r
+            float B = 0.0f;
+            const int iend = min(x, a - 1);
+#pragma unroll 4
+            for (int i = 0; i <= iend; ++i) {
+                float dfa;
+                (void)reg_f<LT>(Gcol[i], gcx, Da[i], dx, dfa);
+                B += dfa;
+            }
+            t -= B;
+        }
+        // ---- row raster, i = a (:58-66).  pairs (j, c): a < j <= c ; delta = G_aj - D_ac (Quirk A)
+        if (x > a) {
+            const LT grx = Grow[x];
+            float A = 0.0f, Sx = 0.0f;
+#pragma unroll 4
+            for (int c = x; c < n; ++c) {              // x plays j
+                float dfa;
+                const float dc = Da[c];
+                Sx += reg_f<LT>(grx, (LT)dc, dx, dc, dfa);
+                A += dfa;
+            }
+            float B = 0.0f;
+            const LT dxg = (LT)dx;
+#pragma unroll 4
+            for (int j = a + 1; j <= x; ++j) {         // x plays c
+                float dfa;
+                (void)reg_f<LT>(Grow[j], dxg, Da[j], dx, dfa);
+                B += dfa;
+            }
+            t += A - B;
+            S += (double)Sx;
+        }
+        Trow[x] = t;
+    }
+    return S;
+}
+
 template <typename GT>
 __global__ __launch_bounds__(256) void k_terms(const float* __restrict__ D, const GT* __restrict__ G,
                                                const int64_t* __restrict__ seg_ptr,
@@ -108,69 +167,42 @@ __global__ __launch_bounds__(256) void k_terms(const float* __restrict__ D, cons
     __syncthreads();
     const SegInfo s = sinfo;
     const int n = s.n, a = (int)(u - s.node0);
-    GT* Gcol = reinterpret_cast<GT*>(smem);            // G[x][a]
-    GT* Grow = Gcol + n;                               // G[a][x]
-    float* Da = reinterpret_cast<float*>(Grow + n);    // D[a][x] == D[x][a] (bitwise symmetric)
     const float* Dseg = D + s.mat0;
     const GT* Gseg = G + s.mat0;
     const float M = __uint_as_float(segM[s.seg]);
+    float* Trow = T + s.mat0 + (long long)a * n;
+
+    // fp64 graph distances that are exactly representable in fp32 (hop counts always are) are held and
+    // compared as fp32: same ordering, full-rate compares, half the LDS bytes.  Anything else stays fp64.
+    float* Gcol_f = reinterpret_cast<float*>(smem);    // G[x][a]
+    float* Grow_f = Gcol_f + n;                        // G[a][x]
+    float* Da_f = Grow_f + n;                          // D[a][x] == D[x][a] (bitwise symmetric)
+    int fits = 1;
     for (int x = threadIdx.x; x < n; x += blockDim.x) {
-        float d = Dseg[(long long)a * n + x];
-        Da[x] = d;
-        Gcol[x] = Gseg[(long long)x * n + a];
-        Grow[x] = Gseg[(long long)a * n + x];
+        const float d = Dseg[(long long)a * n + x];
+        const GT gc = Gseg[(long long)x * n + a], gr = Gseg[(long long)a * n + x];
+        Da_f[x] = d;
+        Gcol_f[x] = (float)gc;
+        Grow_f[x] = (float)gr;
+        fits &= (GT)(float)gc == gc || gc != gc;       // NaN compares as "equal" either way
+        fits &= (GT)(float)gr == gr || gr != gr;
         if (x > a && d == M) atomicMin(&segArg[s.seg], (unsigned long long)a * (unsigned long long)n + x);
     }
-    __syncthreads();
-
-    double S = 0.0;
-    for (int x = threadIdx.x; x < n; x += blockDim.x) {
-        float t = 0.0f;
-        const float dx = Da[x];
-        // ---- column raster, j = a (:49-57).  pairs (i, r): i < a, r >= i, r != a
-        const GT gcx = Gcol[x];
-        if (x < a) {                                   // x plays i
-            float A = 0.0f, Sx = 0.0f;
-            for (int r = x; r < n; ++r) {
-                if (r == a) continue;
-                float dfa;
-                Sx += reg_f(sgn_cmp<GT>(gcx, Gcol[r]), dx, Da[r], dfa);
-                A += dfa;
-            }
-            t += A;
-            S += (double)Sx;
+    double S;
+    if (sizeof(GT) == sizeof(float) || __syncthreads_and(fits)) {
+        if (sizeof(GT) == sizeof(float)) __syncthreads();
+        S = terms_body<float>(Gcol_f, Grow_f, Da_f, n, a, Trow);
+    } else {
+        GT* Gcol = reinterpret_cast<GT*>(smem);
+        GT* Grow = Gcol + n;
+        float* Da = reinterpret_cast<float*>(Grow + n);
+        for (int x = threadIdx.x; x < n; x += blockDim.x) {
+            Da[x] = Dseg[(long long)a * n + x];
+            Gcol[x] = Gseg[(long long)x * n + a];
+            Grow[x] = Gseg[(long long)a * n + x];
         }
-        if (x != a) {                                  // x plays r
-            float B = 0.0f;
-            const int iend = min(x, a - 1);
-            for (int i = 0; i <= iend; ++i) {
-                float dfa;
-                (void)reg_f(sgn_cmp<GT>(Gcol[i], gcx), Da[i], dx, dfa);
-                B += dfa;
-            }
-            t -= B;
-        }
-        // ---- row raster, i = a (:58-66).  pairs (j, c): a < j <= c ; delta = G_aj - D_ac (Quirk A)
-        if (x > a) {
-            const GT grx = Grow[x];
-            float A = 0.0f, Sx = 0.0f;
-            for (int c = x; c < n; ++c) {              // x plays j
-                float dfa;
-                const float dc = Da[c];
-                Sx += reg_f(sgn_cmp<GT>(grx, (GT)dc), dx, dc, dfa);
-                A += dfa;
-            }
-            float B = 0.0f;
-            const GT dxg = (GT)dx;
-            for (int j = a + 1; j <= x; ++j) {         // x plays c
-                float dfa;
-                (void)reg_f(sgn_cmp<GT>(Grow[j], dxg), Da[j], dx, dfa);
-                B += dfa;
-            }
-            t += A - B;
-            S += (double)Sx;
-        }
-        T[s.mat0 + (long long)a * n + x] = t;
+        __syncthreads();
+        S = terms_body<GT>(Gcol, Grow, Da, n, a, Trow);
     }
     // fixed-order block reduction of S
     S = ppk_wave_sum_d(S);

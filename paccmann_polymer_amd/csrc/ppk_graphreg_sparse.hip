@@ -153,12 +153,28 @@ __global__ __launch_bounds__(256) void k_sp_terms(const long long* __restrict__ 
     if ((threadIdx.x & 63) == 0) Spart[gw] = S;
 }
 
-// S = sum of anchor partials in fixed order (single block), S_out[0] = S
-__global__ __launch_bounds__(256) void k_sp_sum(const double* __restrict__ Spart, long long n, double* __restrict__ S_out)
+// S = sum of the per-wave partials of the local anchors' entries, in a fixed order: SUM_BLOCKS blocks each
+// sum one contiguous slice into slice_sum[block] (the last block to finish is NOT special: a second launch
+// adds the slices), so the order never depends on scheduling.
+constexpr int SUM_BLOCKS = 256;
+__global__ __launch_bounds__(256) void k_sp_sum(const double* __restrict__ Spart, const long long* __restrict__ rowptr,
+                                                long long a0, long long a1, double* __restrict__ slice_sum)
 {
     __shared__ double wsum[4];
+    const long long n = ((rowptr[a1] - rowptr[a0] + 255) / 256) * 4;          // waves of k_sp_terms that own entries
+    const long long per = (n + SUM_BLOCKS - 1) / SUM_BLOCKS;
+    const long long i0 = (long long)blockIdx.x * per, i1 = i0 + per < n ? i0 + per : n;
     double acc = 0.0;
-    for (long long i = threadIdx.x; i < n; i += 256) acc += Spart[i];
+    for (long long i = i0 + threadIdx.x; i < i1; i += 256) acc += Spart[i];
+    acc = ppk_wave_sum_d(acc);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) slice_sum[blockIdx.x] = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
+}
+__global__ __launch_bounds__(256) void k_sp_sum2(const double* __restrict__ slice_sum, double* __restrict__ S_out)
+{
+    __shared__ double wsum[4];
+    double acc = threadIdx.x < SUM_BLOCKS ? slice_sum[threadIdx.x] : 0.0;
     acc = ppk_wave_sum_d(acc);
     if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = acc;
     __syncthreads();
@@ -281,13 +297,13 @@ __global__ __launch_bounds__(256) void k_sp_dz_fix(int zdim, long long N, const 
     }
 }
 
-struct SpWs { float* dcsr; float* gcsr; float* T; double* Spart; double* S; unsigned int* Mbits; float* coef; float* head; float* tail; };
+struct SpWs { float* dcsr; float* gcsr; float* T; double* Spart; double* S; unsigned int* Mbits; double* slice; float* coef; float* head; float* tail; };
 inline size_t sp_nwaves(int64_t nnz) { return (size_t)(nnz + 255) / 256 * 4; }              // waves of the terms pass
 inline size_t sp_nchunks(int64_t nnz) { return (size_t)(nnz + DZ_CHUNK - 1) / DZ_CHUNK; }   // waves of the gradient pass
 size_t sp_ws_bytes(int64_t N, int64_t nnz, int64_t zdim)
 {
     (void)N;
-    return 3 * ppk_align_up(sizeof(float) * (size_t)nnz, 256) + ppk_align_up(sizeof(double) * sp_nwaves(nnz), 256) + 2 * 256 +
+    return 3 * ppk_align_up(sizeof(float) * (size_t)nnz, 256) + ppk_align_up(sizeof(double) * sp_nwaves(nnz), 256) + 2 * 256 + ppk_align_up(sizeof(double) * SUM_BLOCKS, 256) +
            (zdim > 0 ? ppk_align_up(sizeof(float) * (size_t)nnz, 256) : 0) +
            2 * ppk_align_up(sizeof(float) * sp_nchunks(nnz) * (size_t)zdim, 256);
 }
@@ -302,6 +318,7 @@ SpWs sp_carve(void* ws, int64_t N, int64_t nnz, int64_t zdim)
     w.Spart = (double*)ppk_carve(cur, sizeof(double) * sp_nwaves(nnz));
     w.S = (double*)ppk_carve(cur, 256);
     w.Mbits = (unsigned int*)ppk_carve(cur, 256);
+    w.slice = (double*)ppk_carve(cur, sizeof(double) * SUM_BLOCKS);
     w.coef = (float*)ppk_carve(cur, sizeof(float) * (size_t)nnz);
     w.head = (float*)ppk_carve(cur, sizeof(float) * sp_nchunks(nnz) * (size_t)zdim);
     w.tail = (float*)ppk_carve(cur, sizeof(float) * sp_nchunks(nnz) * (size_t)zdim);
@@ -378,8 +395,10 @@ int ppk_graphreg_sparse_terms(int64_t N, int64_t E, const int64_t* rowptr, const
     k_sp_terms<<<dim3((unsigned)(nwaves / 4)), dim3(256), 0, stream>>>((const long long*)rowptr, (const long long*)col, w.dcsr, w.gcsr,
                                                                       a0, a1, w.T, w.Spart);
     PPK_CHECK_LAUNCH("k_sp_terms");
-    k_sp_sum<<<dim3(1), dim3(256), 0, stream>>>(w.Spart, nwaves, w.S);
+    k_sp_sum<<<dim3(SUM_BLOCKS), dim3(256), 0, stream>>>(w.Spart, (const long long*)rowptr, a0, a1, w.slice);
     PPK_CHECK_LAUNCH("k_sp_sum");
+    k_sp_sum2<<<dim3(1), dim3(256), 0, stream>>>(w.slice, w.S);
+    PPK_CHECK_LAUNCH("k_sp_sum2");
     return PPK_OK;
 }
 

@@ -110,19 +110,36 @@ def config4(small):
     attr = torch.tensor(rng.integers(1, 4, size=E).astype(np.float32)).cuda()
     graph = SparseRelationGraph(torch.tensor(und).cuda(), attr, N)
     z = torch.randn(N, Z, device='cuda', requires_grad=True)
-    for share, (a0, a1) in (('all anchors (1 GPU holds the whole graph)', (0, N)), ('1/8 of the anchors (one rank of 8)', (0, N // 8))):
+    bal = graph.anchor_ranges(8)
+    cases = [('all anchors (1 GPU holds the whole graph)', (0, N), 1.0)]
+    rp = graph.rowptr.cpu()
+    for name, starts in (('equal node counts', [N * r // 8 for r in range(9)]), ('work-balanced anchor ranges', bal)):
+        for r in range(8):
+            a0, a1 = starts[r], starts[r + 1]
+            cases.append((f'rank {r} of 8, {name}', (a0, a1), float(rp[a1] - rp[a0]) / float(2 * E)))
+    worst = {}
+    for share, (a0, a1), frac in cases:
         wl = f'configs[3]: sparse graph-reg loss, N={N} nodes, E={E} undirected edges, Z={Z}, {share}'
-        frac = (a1 - a0) / N
         by_f = 2 * E * frac * (2 * 4 * Z + 24) + 3 * 2 * E * frac * 4
         loss = _SparseGraphLoss.apply(z, graph, a0, a1, False)
         t_f = timeit(lambda: _SparseGraphLoss.apply(z.detach(), graph, a0, a1, False), iters=5)
-        line('K5 sparse graph loss forward (dist + terms + finish)', wl, t_f, by_f, dict(loss=float(loss)))
 
         def fb():
             z.grad = None
             _SparseGraphLoss.apply(z, graph, a0, a1, False).backward()
         t_fb = timeit(fb, iters=5)
+        if share.startswith('rank'):
+            key = share.split(', ')[1]
+            if key not in worst or t_fb > worst[key][1]:
+                worst[key] = (t_f, t_fb, by_f, share)
+            continue
+        line('K5 sparse graph loss forward (dist + terms + finish)', wl, t_f, by_f, dict(loss=float(loss)))
         line('K5 sparse graph loss forward + backward', wl, t_fb, 2 * by_f + N * Z * 4)
+    for key, (t_f, t_fb, by_f, share) in worst.items():
+        wl = (f'configs[3]: sparse graph-reg loss, N={N} nodes, E={E} undirected edges, Z={Z}, SLOWEST of 8 ranks with {key} '
+              f'({share.split(",")[0]}; each rank timed alone on one GPU)')
+        line('K5 sparse graph loss forward, one rank of 8', wl, t_f, by_f)
+        line('K5 sparse graph loss forward + backward, one rank of 8', wl, t_fb, 2 * by_f + N * Z * 4 / 8)
 
 
 def dense(small):

@@ -17,6 +17,8 @@ SMALL = dict(vocab_size=20, embedding_size=16, rnn_cell_size=32, n_layers=2, sta
              latent_dim=8, dropout=0.0, padding_index=0, batch_size=1, batch_mode='packed')
 ODD = dict(vocab_size=33, embedding_size=10, rnn_cell_size=20, n_layers=3, stack_width=7, stack_depth=4,
            latent_dim=5, dropout=0.0, padding_index=0, batch_size=1, batch_mode='packed')
+ONE = dict(vocab_size=12, embedding_size=8, rnn_cell_size=96, n_layers=1, stack_width=5, stack_depth=3,
+           latent_dim=6, dropout=0.0, padding_index=0, batch_size=1, batch_mode='packed')
 FULL = dict(vocab_size=64, embedding_size=128, rnn_cell_size=512, n_layers=2, stack_width=50, stack_depth=50,
             latent_dim=256, dropout=0.0, padding_index=0, batch_size=1, batch_mode='packed')
 
@@ -54,6 +56,7 @@ def build_pair(params, seed, dtype):
 
 @pytest.mark.parametrize('params,B,lo,hi,seed', [
     (SMALL, 5, 3, 9, 0), (SMALL, 1, 4, 4, 1), (ODD, 7, 3, 12, 2), (SMALL, 9, 5, 5, 3), (FULL, 16, 5, 30, 4),
+    (ONE, 6, 3, 8, 7), (ONE, 140, 2, 6, 8),          # one layer: the recurrent product of the only cell rides with the stack heads
 ])
 def test_train_step_matches_oracle_fp64(params, B, lo, hi, seed):
     check_train_step(params, B, lo, hi, seed)

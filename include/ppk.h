@@ -126,6 +126,15 @@ int ppk_gemm_f32(int transA, int transB, int64_t M, int64_t N, int64_t K, float 
                  float* C, int64_t ldc, const float* bias, void* workspace, size_t ws_bytes,
                  ppk_stream_t stream);
 
+/* C = A^T . B and colsum[m] = sum_k A[k, m] in ONE pass over A (A [K, M], B [K, N], row-major): a weight gradient
+ * dW = dG^T . X together with its bias gradient db = sum_rows dG — the pair torch autograd produces for nn.GRU /
+ * nn.Linear parameters in the reference step (reactions_vae.py:94 loss.backward()).  Fixed-order sums (bitwise
+ * reproducible).  Returns PPK_ERR_UNSUP with nothing launched when the shape does not take the fused kernel
+ * (needs long K >= 8192, N > 192, M % 4 == N % 4 == 0, 16-byte aligned operands): use ppk_gemm_f32 + ppk_colsum.
+ * Workspace: ppk_gemm_f32_workspace_bytes(M, N, K). */
+int ppk_gemm_tn_colsum_f32(int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, const float* B, int64_t ldb,
+                           float* C, int64_t ldc, float* colsum, void* workspace, size_t ws_bytes, ppk_stream_t stream);
+
 /* Tuning / test hook of the NT GEMM family behind ppk_gemm_f32 (NT, K % 32 == 0) and K1: launches
  * whose big-tile grid has at most `limit` tiles run on the small-tile kernels (one 32-row tile per
  * workgroup, K split over its four waves) that keep short packed-batch tail steps — and the

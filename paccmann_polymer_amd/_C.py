@@ -42,6 +42,7 @@ SIGNATURES = {
     'ppk_gemm_f32_workspace_bytes': (c_sz, [c_i64, c_i64, c_i64]),
     'ppk_gemm_f32': (c_int, [c_int, c_int, c_i64, c_i64, c_i64, c_f32, ptr, c_i64, ptr, c_i64, c_f32,
                              ptr, c_i64, ptr, ptr, c_sz, ptr]),
+    'ppk_gemm_tn_colsum_f32': (c_int, [c_i64, c_i64, c_i64, ptr, c_i64, ptr, c_i64, ptr, c_i64, ptr, ptr, c_sz, ptr]),
     'ppk_nt_small_grid_limit': (c_i64, [c_i64]),
     'ppk_stackgru_seq_fwd_workspace_bytes': (c_sz, [c_i64, c_i64, c_i64, c_i64]),
     'ppk_stackgru_seq_fwd': (c_int, [c_i64, ptr, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64,
@@ -81,6 +82,9 @@ SIGNATURES = {
     'ppk_graphreg_sparse_bwd': (c_int, [ptr, c_i64, c_i64, c_i64, c_i64, ptr, ptr, ptr, c_i64, c_i64,
                                         ptr, ptr, c_i64, ptr, c_sz, ptr]),
 }
+
+
+PPK_ERR_UNSUP = -4        # include/ppk.h
 
 
 class PPKError(RuntimeError):

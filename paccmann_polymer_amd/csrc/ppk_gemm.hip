@@ -149,6 +149,8 @@ struct GemmArgs {
     int kslice;          // K elements per slice (multiple of BK)
     float* slabs;        // [ksplit][M][N] when ksplit > 1
     int a_vec, b_vec;    // operand base 16-B aligned and leading dimension % 4 == 0 -> float4 loads
+    float* csum;         // k_tn128 only: csum[m] = sum_k A[k, m] (column sums of the x-contiguous A), or null
+    float* csum_slabs;   // [ksplit][M] when ksplit > 1
 };
 struct GemmBatch { GemmArgs p[1]; };
 
@@ -300,6 +302,11 @@ __global__ __launch_bounds__(256) void k_tn128(const GemmArgs g)
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    // column sums of A (the bias gradient that goes with a weight gradient): the A fragments pass through the
+    // registers of the wn == 0 waves of the first n-tile anyway
+    const bool do_cs = g.csum != nullptr && blockIdx.x == 0 && wn == 0;
+    const float csw = do_cs ? 1.0f : 0.0f;
+    float cs[2] = {0.f, 0.f};
 
     if (nk > 0) stage(0);
     int cur = 0;
@@ -313,6 +320,8 @@ __global__ __launch_bounds__(256) void k_tn128(const GemmArgs g)
             float a[2], b[2];
 #pragma unroll
             for (int i = 0; i < 2; ++i) { a[i] = base[offa[i] + s * 256]; b[i] = base[offb[i] + s * 256]; }
+            cs[0] = fmaf(csw, a[0], cs[0]);              // branch-free: csw = 1 on the waves that own the sums, else 0
+            cs[1] = fmaf(csw, a[1], cs[1]);
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -334,6 +343,7 @@ __global__ __launch_bounds__(256) void k_tn128(const GemmArgs g)
             a[i] = ok ? va : 0.f;
             b[i] = ok ? vb : 0.f;
         }
+        if (do_cs) { cs[0] += a[0]; cs[1] += a[1]; }
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -343,6 +353,15 @@ __global__ __launch_bounds__(256) void k_tn128(const GemmArgs g)
     const bool slab = g.ksplit > 1;
     float* Cout = slab ? g.slabs + (long long)blockIdx.z * g.M * g.N : g.C;
     const long long ldo = slab ? g.N : g.ldc;
+    if (do_cs) {
+        float* co = slab ? g.csum_slabs + (long long)blockIdx.z * g.M : g.csum;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const float t = cs[i] + __shfl_xor(cs[i], 32, 64);                 // even + odd k rows
+            const int m = m0 + wm * 64 + i * 32 + li;
+            if (h == 0 && m < g.M) co[m] = t;
+        }
+    }
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -378,6 +397,12 @@ __global__ __launch_bounds__(256) void k_gemm_reduce(const GemmArgs g)
         if (g.beta != 0.f) v = fmaf(g.beta, *p, v);
         *p = v;
     }
+    if (g.csum)
+        for (long long m = (long long)blockIdx.x * 256 + threadIdx.x; m < g.M; m += (long long)gridDim.x * 256) {
+            float s = 0.f;
+            for (int z = 0; z < g.ksplit; ++z) s += g.csum_slabs[(long long)z * g.M + m];
+            g.csum[m] = s;
+        }
 }
 
 inline long long cdiv(long long a, long long b) { return (a + b - 1) / b; }
@@ -440,6 +465,7 @@ void fill_args(GemmArgs& g, int64_t M, int64_t N, int64_t K, float alpha, const 
     g.a_vec = !(lda & 3) && !((uintptr_t)A & 15);
     g.b_vec = !(ldb & 3) && !((uintptr_t)B & 15);
     g.ksplit = 1; g.kslice = (int)(cdiv(K > 0 ? K : 1, BK) * BK); g.slabs = nullptr;
+    g.csum = nullptr; g.csum_slabs = nullptr;
 }
 
 int check_problem(int transA, int transB, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda,
@@ -472,17 +498,31 @@ size_t gemm_workspace_bytes(int64_t M, int64_t N, int64_t K)
 {
     if (M <= 0 || N <= 0) return 0;
     const Plan pl = make_plan(M, N, K, true);
-    return pl.ksplit > 1 ? ppk_align_up(sizeof(float) * (size_t)M * (size_t)N * (size_t)pl.ksplit, 256) : 0;
+    return pl.ksplit > 1 ? ppk_align_up(sizeof(float) * ((size_t)M * (size_t)N + (size_t)M) * (size_t)pl.ksplit, 256) : 0;
 }
+
+// csum != null: also csum[m] = sum_k A[k, m]; only with the TN fast path (returns PPK_ERR_UNSUP otherwise,
+// before anything is launched, so that the caller can fall back to gemm + colsum)
+int gemm_csum(int transA, int transB, int64_t M, int64_t N, int64_t K, float alpha,
+              const float* A, int64_t lda, const float* B, int64_t ldb, float beta,
+              float* C, int64_t ldc, const float* bias, float* csum, void* ws, size_t ws_bytes, hipStream_t stream);
 
 int gemm(int transA, int transB, int64_t M, int64_t N, int64_t K, float alpha,
          const float* A, int64_t lda, const float* B, int64_t ldb, float beta,
          float* C, int64_t ldc, const float* bias, void* ws, size_t ws_bytes, hipStream_t stream)
 {
+    return gemm_csum(transA, transB, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, bias, nullptr, ws, ws_bytes, stream);
+}
+
+int gemm_csum(int transA, int transB, int64_t M, int64_t N, int64_t K, float alpha,
+              const float* A, int64_t lda, const float* B, int64_t ldb, float beta,
+              float* C, int64_t ldc, const float* bias, float* csum, void* ws, size_t ws_bytes, hipStream_t stream)
+{
     if (M == 0 || N == 0) return PPK_OK;
     int rc = check_problem(transA, transB, M, N, K, A, lda, B, ldb, C, ldc);
     if (rc) return rc;
     const bool a_kc = !transA, b_kc = transB != 0;
+    if (csum && (a_kc || b_kc)) PPK_FAIL(PPK_ERR_UNSUP, "gemm_csum: TN layout only");
     GemmBatch gb;
     GemmArgs& g = gb.p[0];
     fill_args(g, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, bias);
@@ -497,16 +537,19 @@ int gemm(int transA, int transB, int64_t M, int64_t N, int64_t K, float alpha,
         return gemm_nt64(&p, 1, stream);
     }
     if (pl.ksplit > 1) {
-        const size_t need = sizeof(float) * (size_t)M * (size_t)N * (size_t)pl.ksplit;
+        const size_t need = sizeof(float) * ((size_t)M * (size_t)N + (size_t)M) * (size_t)pl.ksplit;
         if (need <= ws_bytes) {
             g.kslice = (int)(cdiv(cdiv(K, pl.ksplit), BK) * BK);
             g.ksplit = (int)cdiv(K, g.kslice);
             g.slabs = (float*)ws;
+            g.csum_slabs = g.slabs + (size_t)M * (size_t)N * (size_t)pl.ksplit;
         }
     }
     const char* tn_env = getenv("PPK_GEMM_TN");                       // tuning aid: 0 keeps the register-staged kernel
     const bool tn_fast = !a_kc && !b_kc && pl.tile == 2 && g.a_vec && g.b_vec && !(M & 3) && !(N & 3) && M >= 4 && N >= 4 &&
                          !(tn_env && atoi(tn_env) == 0);
+    if (csum && !tn_fast) PPK_FAIL(PPK_ERR_UNSUP, "gemm_csum: the fused column sum needs the TN fast path (long K, N > 192, M, N %% 4 == 0, aligned operands)");
+    g.csum = csum;
     if (tn_fast) {
         ppk::ProfScope prof(PK_GEMM_TN128, 2.0 * (double)M * (double)N * (double)K, stream);
         k_tn128<<<dim3((unsigned)cdiv(N, 128), (unsigned)cdiv(M, 128), (unsigned)g.ksplit), dim3(256), 0, stream>>>(g);
@@ -531,6 +574,17 @@ extern "C" {
 size_t ppk_gemm_f32_workspace_bytes(int64_t M, int64_t N, int64_t K)
 {
     return ppk::gemm_workspace_bytes(M, N, K);
+}
+
+// C = A^T . B  and  colsum[m] = sum_k A[k, m]  in one pass over A (A [K, M], B [K, N], both x-contiguous): a weight
+// gradient and the bias gradient that goes with it.  Returns PPK_ERR_UNSUP (nothing launched) when the shape does
+// not take the fused kernel; the caller then uses ppk_gemm_f32 + ppk_colsum.
+int ppk_gemm_tn_colsum_f32(int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, const float* B, int64_t ldb,
+                           float* C, int64_t ldc, float* colsum, void* workspace, size_t ws_bytes, hipStream_t stream)
+{
+    if (!colsum) { ppk_set_error("gemm_tn_colsum: null colsum"); return PPK_ERR_NULL; }
+    if (M == 0 || N == 0) return PPK_OK;
+    return ppk::gemm_csum(1, 0, M, N, K, 1.0f, A, lda, B, ldb, 0.0f, C, ldc, nullptr, colsum, workspace, ws_bytes, stream);
 }
 
 int ppk_gemm_f32(int transA, int transB, int64_t M, int64_t N, int64_t K, float alpha,

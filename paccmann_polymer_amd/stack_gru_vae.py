@@ -22,6 +22,7 @@ Restrictions of the HIP path (raise instead of silently falling back):
 packed batches (`PackedSequence`), fp32.
 """
 import ctypes
+import os
 from typing import Optional
 
 import torch
@@ -321,6 +322,18 @@ class _StackGRUSeq(torch.autograd.Function):
             _C.check(_lib.ppk_colsum(_C.p(A), lda, NT, C, 0.0, _C.p(out), _C.p(cws), cws_b, st))
             return out
 
+        def tn_colsum(A, lda, M, Bm, ldb, N):
+            """(A^T . B, column sums of A): one pass over A when the fused kernel takes the shape."""
+            if os.environ.get('PPK_FUSED_COLSUM', '1') == '0':          # tuning aid
+                return tn(A, lda, M, Bm, ldb, N), colsum(A, lda, M)
+            out = torch.empty(M, N, **f32)
+            cs = torch.empty(M, **f32)
+            rc = _lib.ppk_gemm_tn_colsum_f32(M, N, NT, _C.p(A), lda, _C.p(Bm), ldb, _C.p(out), N, _C.p(cs), _C.p(gws), gws_b, st)
+            if rc == _C.PPK_ERR_UNSUP:
+                return tn(A, lda, M, Bm, ldb, N), colsum(A, lda, M)
+            _C.check(rc)
+            return out, cs
+
         def w_grad(g):          # [3Hp, Hp] -> [3H, H]
             return _unpad_units(_unpad_units(g, H, Hp, 0, 3), H, Hp, 1)
 
@@ -334,19 +347,17 @@ class _StackGRUSeq(torch.autograd.Function):
         _gemm(0, 0, V, E, 3 * Hp, dtable, 3 * Hp, w0, E + W, demb, E)         # dtable . W_ih0[:, :E]
         if ctx.padding_idx >= 0:
             demb[ctx.padding_idx].zero_()
+        dwhh0, dbhh0 = tn_colsum(DGH[0], 3 * Hp, 3 * Hp, HP[0], Hp, Hp)
         gru_grads = [
             _unpad_units(torch.cat([dw0e, dw0s], dim=1), H, Hp, 0, 3),
-            w_grad(tn(DGH[0], 3 * Hp, 3 * Hp, HP[0], Hp, Hp)),
-            _unpad_units(colsum(DGI[0], 3 * Hp, 3 * Hp), H, Hp, 0, 3),
-            _unpad_units(colsum(DGH[0], 3 * Hp, 3 * Hp), H, Hp, 0, 3),
+            w_grad(dwhh0),
+            _unpad_units(dtable.sum(0), H, Hp, 0, 3),            # sum_rows DGI0 = sum over tokens of the per-token sums
+            _unpad_units(dbhh0, H, Hp, 0, 3),
         ]
         for l in range(1, L):
-            gru_grads += [
-                w_grad(tn(DGI[l], 3 * Hp, 3 * Hp, Hs[l - 1], Hp, Hp)),
-                w_grad(tn(DGH[l], 3 * Hp, 3 * Hp, HP[l], Hp, Hp)),
-                _unpad_units(colsum(DGI[l], 3 * Hp, 3 * Hp), H, Hp, 0, 3),
-                _unpad_units(colsum(DGH[l], 3 * Hp, 3 * Hp), H, Hp, 0, 3),
-            ]
+            dwih, dbih = tn_colsum(DGI[l], 3 * Hp, 3 * Hp, Hs[l - 1], Hp, Hp)
+            dwhh, dbhh = tn_colsum(DGH[l], 3 * Hp, 3 * Hp, HP[l], Hp, Hp)
+            gru_grads += [w_grad(dwih), w_grad(dwhh), _unpad_units(dbih, H, Hp, 0, 3), _unpad_units(dbhh, H, Hp, 0, 3)]
         dwcs = _unpad_units(tn(DCS, ldcs, 3 + W, HP[L - 1], Hp, Hp), H, Hp, 1)
         dbcs = colsum(DCS, ldcs, 3 + W)
         dh0 = _unpad_units(dh0, H, Hp, 2)

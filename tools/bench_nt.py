@@ -7,13 +7,17 @@ import torch
 from paccmann_polymer_amd import ops
 
 
-def bench(M, N, K, iters=20):
+def bench(M, N, K, iters=20, check=True):
     A = torch.randn(M, K, device='cuda')
     B = torch.randn(N, K, device='cuda') * 0.05
     C = torch.empty(M, N, device='cuda')
     for _ in range(3):
         ops.gemm(A, B, False, True, C=C)
     torch.cuda.synchronize()
+    if check:
+        ref = A.double() @ B.double().T
+        err = (C.double() - ref).abs().max().item() / (ref.abs().max().item() + 1e-30)
+        assert err < 1e-5, err
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(iters):

@@ -12,7 +12,6 @@
 // kept, nothing is recomputed):  rows of step t live at packed offset
 // off[t] .. off[t]+B_t in sorted order, so "hidden of the previous step" for the
 // active prefix is simply the row block of step t-1 — no copies, no masking.
-//   X     [NT, ldx]   layer-0 input  [embedding | stack top]
 //   Hs    [L, NT, H]  hidden after the step          HP [L, NT, H] hidden before it
 //   gates [L, NT, 4H] r, z, n, (W_hn h + b_hn)
 //   S     [NT, D, W]  stack after the step           CS [NT, ldcs] softmax(3) | tanh(W)
@@ -22,8 +21,8 @@
 // 3-6 GFLOP, far above the ~1.5 us kernel boundary, while a persistent
 // LDS-resident-weights kernel would pay a 4-6 us grid barrier per layer-step
 // (MI355X_MICROARCH.md price list) — see DESIGN.md.
-// Per step (forward):   stack update -> cell 0 {K = ks, + table[token]} -> for l >= 1
-// {cell l ; W_hh[l-1] h for the NEXT step} -> {W_hh[L-1] h ; stack heads} for the next step.
+// Per step (forward):   stack update -> {cell 0 (K = ks, + table[token]) ; W_hh[L-1] h of the previous step}
+// -> for l >= 1 {cell l ; W_hh[l-1] h for the NEXT step} -> stack heads for the next step.
 // The embedding half of the layer-0 input product is hoisted out of the time loop:
 // table[v] = emb[v] . W_ih0[:, :E]^T + b_ih0 is a [V, 3H] lookup.
 #include "ppk_common.h"

@@ -226,6 +226,17 @@ int ppk_reparam_bwd(const float* mu, const float* logvar, const float* eps, int6
 int ppk_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
                   float lr, float beta1, float beta2, float eps, float weight_decay, int64_t step, ppk_stream_t stream);
 
+/* ---- batched hop-distance matrices of bundle graphs ------
+ * Replaces, per bundle, reactions_vae.py:79-83 (nx.from_edgelist + add_nodes_from + floyd_warshall_numpy, inf -> 0):
+ * undirected all-pairs hop counts as fp64, 0 for unreachable pairs and the diagonal, rows in networkx node INSERTION
+ * order (networkx_order != 0; Quirk C) or in index order.  esrc / edst [E_total]: LOCAL labels 0 .. n_k - 1 of the
+ * concatenated edge lists; edge_ptr / seg_ptr / mat_ptr [n_seg + 1]: device prefix arrays over edges, nodes, n_k^2.
+ * G [mat_ptr[n_seg]]; order_out [seg_ptr[n_seg]] (may be NULL): original label of each row; status [1] device int,
+ * non-zero when a label was out of range (those edges are skipped).  Bundles of at most 64 nodes (max_n). */
+int ppk_hop_distances(const int64_t* esrc, const int64_t* edst, const int64_t* edge_ptr, const int64_t* seg_ptr,
+                      const int64_t* mat_ptr, int64_t n_seg, int64_t max_n, int networkx_order,
+                      double* G, int64_t* order_out, int* status, ppk_stream_t stream);
+
 /* ---- K6: CSR build (stable sort of edge_index by target) --------------------
  * gcn_norm + the grouping that torch_scatter.scatter_add performs implicitly inside
  * torch_geometric GCNConv (reference reactions_infomax.py:60,66).

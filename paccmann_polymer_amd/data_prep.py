@@ -4,6 +4,7 @@ Mirrors
   experiments/chem_reactions/utils.py:35-98    packed_sequential_data_preparation
   experiments/chem_reactions/reactions_vae.py:79-83   hop-distance matrix (Floyd–Warshall, networkx order)
   experiments/chem_reactions/utils.py:155-196  bundle sampler of load_data
+(`hop_distance_matrices_device`: the same matrices for a whole step's bundles in one HIP launch)
 with bit-exact integer outputs (tests/test_data_prep.py pins them against
 torch.nn.utils.rnn.pack_sequence and networkx run on the same statements).
 """
@@ -106,6 +107,45 @@ def hop_distance_matrix(edge_index, num_nodes: int, order: str = 'networkx') -> 
         reach = seen > 0
         dist[s, reach] = seen[reach]
     return dist
+
+
+def hop_distance_matrices_device(edge_indices, num_nodes, order: str = 'networkx', device=None):
+    """Batched device version of `hop_distance_matrix` (kernel `ppk_hop_distances`): one launch for all
+    bundles of a step.  `edge_indices`: sequence of [2, E_k] integer arrays / tensors with LOCAL labels;
+    `num_nodes`: sequence of n_k (each <= 64).  Returns (g_flat float64 device tensor holding the n_k x n_k
+    matrices back to back — the layout `graph_loss_segmented` takes —, sizes, row_order int64 device tensor:
+    original label of every row).  Raises IndexError on labels outside [0, n_k)."""
+    from . import _C
+    if order not in ('networkx', 'index'):
+        raise ValueError(order)
+    if device is None:
+        device = torch.device('cuda')
+    sizes = [int(n) for n in num_nodes]
+    if len(sizes) != len(edge_indices) or not sizes:
+        raise ValueError()
+    eis = [np.asarray(e.cpu() if torch.is_tensor(e) else e, dtype=np.int64).reshape(2, -1) for e in edge_indices]
+    edge_ptr = np.zeros(len(sizes) + 1, dtype=np.int64)
+    edge_ptr[1:] = np.cumsum([e.shape[1] for e in eis])
+    seg_ptr = np.zeros(len(sizes) + 1, dtype=np.int64)
+    seg_ptr[1:] = np.cumsum(sizes)
+    mat_ptr = np.zeros(len(sizes) + 1, dtype=np.int64)
+    mat_ptr[1:] = np.cumsum([n * n for n in sizes])
+    packed = np.concatenate([np.concatenate(eis, axis=1).reshape(-1), edge_ptr, seg_ptr, mat_ptr])
+    dev = torch.from_numpy(packed).to(device)                       # one host -> device copy
+    E = int(edge_ptr[-1])
+    K = len(sizes)
+    esrc, edst = dev[:E], dev[E:2 * E]
+    o = 2 * E
+    d_edge_ptr, d_seg_ptr, d_mat_ptr = dev[o:o + K + 1], dev[o + K + 1:o + 2 * K + 2], dev[o + 2 * K + 2:o + 3 * K + 3]
+    g = torch.empty(int(mat_ptr[-1]), dtype=torch.float64, device=device)
+    row_order = torch.empty(int(seg_ptr[-1]), dtype=torch.int64, device=device)
+    status = torch.zeros(1, dtype=torch.int32, device=device)
+    _C.check(_C.lib.ppk_hop_distances(_C.p(esrc) if E else None, _C.p(edst) if E else None, _C.p(d_edge_ptr), _C.p(d_seg_ptr),
+                                      _C.p(d_mat_ptr), K, max(sizes), 1 if order == 'networkx' else 0,
+                                      _C.p(g), _C.p(row_order), _C.p(status), _C.stream()))
+    if int(status.item()) != 0:
+        raise IndexError('edge_index holds a node label outside [0, num_nodes)')
+    return g, sizes, row_order
 
 
 def sample_bundle(neighbors, root, max_close_neighbors=5, max_total_bundle=20, rng=np.random):

@@ -15,7 +15,7 @@ from typing import Optional, Sequence
 import numpy as np
 import torch
 
-from .data_prep import hop_distance_matrix, packed_sequential_data_preparation
+from .data_prep import hop_distance_matrices_device, hop_distance_matrix, packed_sequential_data_preparation
 from .graph_constrained_loss import graph_loss, graph_loss_segmented
 from .paccmann_encoder import get_device
 
@@ -68,7 +68,11 @@ def train(epoch, model, train_loader, optimizer, scheduler, graph_gamma, growth_
             seqs, input_keep=input_keep, start_index=start_index, end_index=end_index, device=device)
         optimizer.zero_grad()
         decoder_loss, mu, logvar, z = model.train_step(encoder_seq, decoder_seq, target_seq)
-        dists = torch.tensor(hop_distance_matrix(data.edge_index, batch_size, order=distance_order)).to(device)
+        if batch_size <= 64:                                            # one HIP launch (ppk_hop_distances), same integers
+            flat, _, _ = hop_distance_matrices_device([data.edge_index], [batch_size], order=distance_order, device=device)
+            dists = flat.view(batch_size, batch_size)
+        else:
+            dists = torch.tensor(hop_distance_matrix(data.edge_index, batch_size, order=distance_order)).to(device)
         kl_scale = kl_schedule(epoch, _iter, n_iter, growth_rate)       # computed, unused (as in the reference)
         z = z.squeeze()
         gr_loss = graph_loss(z, dists)

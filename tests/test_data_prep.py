@@ -93,3 +93,20 @@ def test_bundle_sampler_and_relabel_match_networkx(seed):
     labels, ei = DP.relabel_bundle(shortlist)
     assert labels == want_labels
     assert np.array_equal(ei, want_ei)
+
+
+@pytest.mark.parametrize('B,lo,hi,seed', [(1, 1, 1, 0), (300, 1, 6, 1), (2048, 20, 100, 2), (17, 5, 5, 3)])
+def test_packed_preparation_vectorised_path_is_bit_exact(B, lo, hi, seed):
+    """input_keep == 1 takes the loop-free path: same data, batch_sizes and tie order as pack_sequence."""
+    rng = np.random.default_rng(seed)
+    seqs = [torch.tensor(rng.integers(2, 60, size=int(rng.integers(lo, hi + 1)))) for _ in range(B)]
+    enc, dec, tgt = DP.packed_sequential_data_preparation(seqs, input_keep=1., device='cpu')
+    ref = pack_sequence(seqs, enforce_sorted=False)
+    ref_t = pack_sequence([torch.cat([s[1:], torch.tensor([0])]) for s in seqs], enforce_sorted=False)
+    for got, want in ((enc, ref), (dec, ref), (tgt, ref_t)):
+        assert torch.equal(got.data, want.data)
+        assert torch.equal(got.batch_sizes, want.batch_sizes) and got.batch_sizes.device.type == 'cpu'
+        assert torch.equal(got.sorted_indices, want.sorted_indices)
+        assert torch.equal(got.unsorted_indices, want.unsorted_indices)
+    dec.data[0] = -7                                   # the decoder stream is its own storage (reference: input.clone())
+    assert enc.data[0] != -7

@@ -73,6 +73,59 @@ __global__ __launch_bounds__(256) void k_dist(const float* __restrict__ z, long 
     if (lane == 0 && mx > 0.0f) atomicMax(&segM[s.seg], __float_as_uint(mx));   // D >= 0: uint order == float order
 }
 
+// ---------------------------------------------------------------- k_dist_tiled
+// One large dense graph (n_seg == 1): 64 x 64 tiles of D, the two row blocks staged through LDS in chunks of
+// 32 latent dimensions, 4 x 4 pairs per thread.  Direct differences accumulated in ascending k for BOTH (u, v)
+// and (v, u), so D stays bitwise symmetric (k_terms relies on it).  k_dist (a wave per pair, tree reduction)
+// spends its time in the reductions: 0.77 ms at N = 2048, Z = 256.
+__global__ __launch_bounds__(256) void k_dist_tiled(const float* __restrict__ z, long long ldz, int zdim, int n,
+                                                    float* __restrict__ D, unsigned int* __restrict__ segM)
+{
+    __shared__ float zu[64][33], zv[64][33];
+    const int u0 = blockIdx.y * 64, v0 = blockIdx.x * 64;
+    const int tid = threadIdx.x, ty = tid >> 4, tx = tid & 15;
+    float acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
+    for (int k0 = 0; k0 < zdim; k0 += 32) {
+        __syncthreads();
+        for (int e = tid; e < 64 * 32; e += 256) {
+            const int r = e >> 5, k = e & 31;
+            const bool kin = k0 + k < zdim;
+            zu[r][k] = (kin && u0 + r < n) ? z[(long long)(u0 + r) * ldz + k0 + k] : 0.f;
+            zv[r][k] = (kin && v0 + r < n) ? z[(long long)(v0 + r) * ldz + k0 + k] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll 8
+        for (int k = 0; k < 32; ++k) {
+            float a[4], b[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { a[i] = zu[ty * 4 + i][k]; b[i] = zv[tx * 4 + i][k]; }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { const float d = a[i] - b[j]; acc[i][j] = fmaf(d, d, acc[i][j]); }
+        }
+    }
+    float mx = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int u = u0 + ty * 4 + i, v = v0 + tx * 4 + j;
+            if (u < n && v < n) {
+                const float dist = u == v ? 0.f : sqrtf(acc[i][j]);
+                D[(long long)u * n + v] = dist;
+                mx = fmaxf(mx, dist);
+            }
+        }
+    mx = ppk_wave_max(mx);
+    if ((tid & 63) == 0 && mx > 0.f && __float_as_uint(mx) > __hip_atomic_load(segM, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+        atomicMax(segM, __float_as_uint(mx));
+}
+
 // graph_regularizer_function (:4-10) for delta = g1 - g2: value and d/d(di); d/d(dj) = -that.
 //   delta == 0 -> (di - dj)^2 ; delta > 0 -> relu(dj - di) ; delta < 0 -> relu(di - dj)
 // Written with selects only: the three-way branch cost ~40 instructions per evaluation with divergent
@@ -365,8 +418,14 @@ int ppk_graphreg_dense_fwd(const float* z, int64_t ldz, const void* g, int g_dty
     DenseWs w = dense_ws_carve(workspace, n_seg, n_total, sum_n2);
     PPK_HIP(hipMemsetAsync(w.segM, 0, sizeof(unsigned int) * (size_t)n_seg, stream));
     PPK_HIP(hipMemsetAsync(w.segArg, 0xff, sizeof(unsigned long long) * (size_t)n_seg, stream));
-    k_dist<<<dim3((unsigned)n_total), dim3(256), 0, stream>>>(z, ldz, (int)zdim, seg_ptr, mat_ptr, (int)n_seg, w.D, w.segM);
-    PPK_CHECK_LAUNCH("k_dist");
+    if (n_seg == 1 && max_n >= 128 && max_n == n_total) {
+        const unsigned t = (unsigned)((n_total + 63) / 64);
+        k_dist_tiled<<<dim3(t, t), dim3(256), 0, stream>>>(z, ldz, (int)zdim, (int)n_total, w.D, w.segM);
+        PPK_CHECK_LAUNCH("k_dist_tiled");
+    } else {
+        k_dist<<<dim3((unsigned)n_total), dim3(256), 0, stream>>>(z, ldz, (int)zdim, seg_ptr, mat_ptr, (int)n_seg, w.D, w.segM);
+        PPK_CHECK_LAUNCH("k_dist");
+    }
     const unsigned tb = max_n <= 64 ? 64u : 256u;
     if (g_dtype == PPK_F64) {
         size_t lds = (size_t)max_n * (8 + 8 + 4);

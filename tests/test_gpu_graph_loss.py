@@ -67,7 +67,7 @@ def test_upstream_gradient_scales():
     assert rel(dz, -2.5 * g['dz']) <= 1e-4
 
 
-@pytest.mark.parametrize('n,zd,seed', [(33, 64, 1), (100, 256, 2), (257, 32, 3)])
+@pytest.mark.parametrize('n,zd,seed', [(33, 64, 1), (100, 256, 2), (257, 32, 3), (130, 50, 4)])
 def test_dense_vs_oracle_larger(n, zd, seed):
     from oracle import graph_loss_oracle as O
     import networkx as nx

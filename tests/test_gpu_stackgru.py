@@ -162,3 +162,18 @@ def test_rejects_cpu_and_unpacked():
         enc.encoder_train_step(torch.zeros(4, 2, dtype=torch.int64))
     with pytest.raises(IndexError):
         enc.encoder_train_step(pack_sequence([torch.tensor([2, 99, 3])]))
+
+
+@pytest.mark.parametrize('seed', range(10))
+def test_train_step_random_configurations(seed):
+    """Random model / batch shapes against the fp64 oracle: hidden sizes off the 32-unit grid, 1..4 layers,
+    stack widths across the 32-column padding boundary, batches across the row-tile boundaries."""
+    rng = np.random.default_rng(1000 + seed)
+    params = dict(vocab_size=int(rng.integers(6, 70)), embedding_size=int(rng.integers(3, 40)),
+                  rnn_cell_size=int(rng.choice([8, 20, 32, 33, 64, 72, 96, 130])), n_layers=int(rng.integers(1, 5)),
+                  stack_width=int(rng.choice([3, 7, 29, 32, 33, 50])), stack_depth=int(rng.integers(2, 9)),
+                  latent_dim=int(rng.integers(2, 20)), dropout=0.0, padding_index=0, batch_size=1, batch_mode='packed')
+    B = int(rng.choice([1, 2, 31, 33, 65, 129, 200]))
+    lo = int(rng.integers(2, 5))
+    hi = lo + int(rng.integers(0, 9))
+    check_train_step(params, B, lo, hi, 2000 + seed)

@@ -13,13 +13,18 @@
 // which makes every ds_read_b128 lane group hit 16 distinct bank quads).
 // One raw s_barrier per K tile, counted vmcnt so the next tiles stay in flight.
 //
-// Two tile shapes (measured on MI355X, tools/gemm_lab3.hip):
-//   k_nt64  64 x 64, 4 waves 2x2, 1 accumulator per wave, 4 LDS buffers    — generic, many small tiles
+// Four kernels (measured on MI355X: tools/gemm_lab3.hip, tools/bench_nt*.py):
+//   k_nt64  64 x 64, 4 waves 2x2, 1 accumulator per wave, 4 LDS buffers    — generic, two co-resident workgroups per CU
 //   k_ntF   128 x (3 x 32) "gate layout", 4 waves along M, 3 accumulators   — a lane holds r, z, n of one
-//           (row, hidden unit), so the GRU cell is evaluated in registers.
-// Measured limiter: every ds_read_b128 costs the matrix pipe ~18 cycles (the
-// LDS return shares the register-file write path with the MFMA write-back), so
-// fewer LDS bytes per MFMA (3 accumulators per A fragment) is what pays.
+//           (row, hidden unit), so the GRU cell is evaluated in registers
+//   k_nt32 / k_ntFs   the same two shapes on 32-row tiles with K split over the waves (no barrier in the main
+//           loop) for the short tail steps; the host picks the family per launch from a fitted cost model.
+// A launch is a 1-D grid over the tiles of up to four problems, remapped so that every XCD gets a contiguous
+// run of every problem's tiles (nt_tile).  Epilogue operands are prefetched into registers before the K loop;
+// the bodies are instantiated per epilogue mode so that the outstanding-load counts stay compile-time constants.
+// Every inner-loop variant tried lands at 70-81 % of the MFMA rate and every launch carries ~8 us that do not
+// scale with K; the dead ends (deeper prefetch, 128 x 64 tiles, K-split 64 x 64, two accumulator chains, wave
+// priorities) are listed in DESIGN.md.
 #include "ppk_common.h"
 #include "ppk_kernels.h"
 #include <stdlib.h>

@@ -154,7 +154,9 @@ int64_t ppk_nt_small_grid_limit(int64_t limit);
  * is split: table [V, 3H] = embedding.weight . weight_ih_l0[:, :E]^T + bias_ih_l0 (a
  * lookup per token, hoisted out of the time loop) and wx0s [3H, ks] = weight_ih_l0[:, E:E+W]
  * zero padded to ks = W rounded up to 32.  wcs [3+W, H] / bcs [3+W] are
- * stack_controls_layer rows 0..2 followed by stack_input_layer; h0 [L, B, H].
+ * stack_controls_layer rows 0..2 followed by stack_input_layer; h0 [L, B, H]; S0 [B, D, W] = stack entering
+ * step 0 (NULL = zeros: training starts from the empty stack; the single-step decoder call of
+ * paccmann_encoder.py:115-131 -> TeacherVAE.generate carries it from token to token).
  * H must be a multiple of 32 (the host side pads with zero units); ldcs = 3+W rounded up to 32.
  * Per step: stack update, then one MFMA GEMM launch per layer with the GRU gate math in
  * its epilogue (plus the recurrent products needed by the next step).
@@ -167,7 +169,7 @@ int ppk_stackgru_seq_fwd(int64_t T, const int64_t* batch_sizes_host, int64_t B, 
                          const int64_t* tokens, const float* table, const float* wx0s, int64_t ks,
                          const float* const* w_ih, const float* const* w_hh,
                          const float* const* b_ih, const float* const* b_hh,
-                         const float* wcs, const float* bcs, const float* h0,
+                         const float* wcs, const float* bcs, const float* h0, const float* S0,
                          float* XS, float* Hs, float* HP, float* gates, float* S,
                          float* CS, int64_t ldcs, void* workspace, size_t ws_bytes, ppk_stream_t stream);
 /* dHtop [NT, H] = gradient at the top layer's output of every step.  Outputs:

@@ -47,7 +47,7 @@ SIGNATURES = {
     'ppk_hop_distances': (c_int, [ptr, ptr, ptr, ptr, ptr, c_i64, c_i64, c_int, ptr, ptr, ptr, ptr]),
     'ppk_stackgru_seq_fwd_workspace_bytes': (c_sz, [c_i64, c_i64, c_i64, c_i64]),
     'ppk_stackgru_seq_fwd': (c_int, [c_i64, ptr, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64,
-                                     ptr, ptr, ptr, c_i64, ptr, ptr, ptr, ptr, ptr, ptr, ptr,
+                                     ptr, ptr, ptr, c_i64, ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr,
                                      ptr, ptr, ptr, ptr, ptr, ptr, c_i64, ptr, c_sz, ptr]),
     'ppk_stackgru_seq_bwd_workspace_bytes': (c_sz, [c_i64, c_i64, c_i64]),
     'ppk_stackgru_seq_bwd': (c_int, [c_i64, ptr, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64,

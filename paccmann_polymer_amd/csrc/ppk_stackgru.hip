@@ -222,13 +222,14 @@ size_t ppk_stackgru_seq_fwd_workspace_bytes(int64_t B, int64_t H, int64_t L, int
 
 // table [V, 3H]  = emb . W_ih0[:, :E]^T + b_ih0      (embedding half of the layer-0 input product)
 // wx0s  [3H, ks] = W_ih0[:, E:E+W], zero padded       (stack half)
-// w_ih[l], b_ih[l] are read for l >= 1 only.
+// w_ih[l], b_ih[l] are read for l >= 1 only.  S0 [B, D, W]: stack entering step 0, NULL = zeros (training always
+// starts from the empty stack; single-step generation carries it).
 int ppk_stackgru_seq_fwd(int64_t T, const int64_t* batch_sizes_host, int64_t B, int64_t NT,
                          int64_t V, int64_t H, int64_t L, int64_t W, int64_t D,
                          const int64_t* tokens, const float* table, const float* wx0s, int64_t ks,
                          const float* const* w_ih, const float* const* w_hh,
                          const float* const* b_ih, const float* const* b_hh,
-                         const float* wcs, const float* bcs, const float* h0,
+                         const float* wcs, const float* bcs, const float* h0, const float* S0,
                          float* XS, float* Hs, float* HP, float* gates, float* S,
                          float* CS, int64_t ldcs, void* workspace, size_t ws_bytes, hipStream_t stream)
 {
@@ -274,7 +275,7 @@ int ppk_stackgru_seq_fwd(int64_t T, const int64_t* batch_sizes_host, int64_t B, 
         auto hprev = [&](int64_t l) { return t == 0 ? h0 + l * B * H : Hs + (l * NT + op) * H; };
         { ppk::ProfScope prof(ppk::PK_STACK_FWD, 8.0 * (double)Bt * D * W, stream);
         k_stack_fwd<<<dim3((unsigned)Bt), dim3(256), lds_stack, stream>>>(
-            csraw, ldcs, t == 0 ? nullptr : S + op * D * W, S + o * D * W, CS + o * ldcs, XS + o * ks, ks, (int)D, (int)W); }
+            csraw, ldcs, t == 0 ? S0 : S + op * D * W, S + o * D * W, CS + o * ldcs, XS + o * ks, ks, (int)D, (int)W); }
         PPK_CHECK_LAUNCH("k_stack_fwd");
         for (int64_t l = 0; l < L; ++l) {
             ppk::NtProblem ps[2];

@@ -2,15 +2,16 @@
 `paccmann_polymer/models/paccmann_encoder.py::Encoder` (:15-169): same
 constructor arguments, attributes (`gru_encoder`, `gru_decoder`, `gru_vae`,
 `smiles_language`, `transform`, `device`) and methods.  `train_step` (:141-169)
-is the hot path; the sampling / SMILES text side (`decode`, `reconstruct`,
-pytoda `SMILESLanguage`) is SURVEY §8f "next" and raises NotImplementedError.
+is the hot path.  `decode` / `reconstruct` (:115-139) run token generation through the single-step
+kernels (`TeacherVAE.generate`, build-defined: the upstream body is not in the reference tree); the SMILES
+text side uses a minimal character-level `TokenLanguage` in place of pytoda's `SMILESLanguage`.
 """
 import json
 from typing import Optional, Union
 
 import torch
 
-from .stack_gru_vae import StackGRUDecoder, StackGRUEncoder, TeacherVAE
+from .stack_gru_vae import SamplingSearch, StackGRUDecoder, StackGRUEncoder, TeacherVAE
 
 
 def get_device():
@@ -34,6 +35,11 @@ class TokenLanguage:
 
     def smiles_to_token_indexes(self, smiles: str):
         return [self.start_index] + [self.token_to_index.get(c, self.unknown_index) for c in smiles] + [self.stop_index]
+
+    def token_indexes_to_smiles(self, token_indexes):
+        index_to_token = {v: k for k, v in self.token_to_index.items()}
+        special = (self.padding_index, self.start_index, self.stop_index)
+        return ''.join(index_to_token.get(int(t), '?') for t in token_indexes if int(t) not in special)
 
 
 class Encoder:
@@ -96,10 +102,24 @@ class Encoder:
         return self.encode(pack_sequence([tokens.cpu()])).detach().squeeze()
 
     def decode(self, latent_z, generate_len=100, search=None):
-        raise NotImplementedError('sampling-based generation is outside the training hot path (SURVEY §8f item 3)')
+        """Reference :115-131: seeds the torch RNG with `self.seed`, generates from `latent_z [B, Z]`, returns one
+        token list per sample starting with the start index."""
+        latent_z = latent_z.view(1, latent_z.shape[0], latent_z.shape[1]).float()
+        torch.manual_seed(self.seed)
+        molecule_iter = self.gru_vae.generate(
+            latent_z,
+            prime_input=torch.tensor([self.smiles_language.start_index]).to(self.device),
+            end_token=torch.tensor([self.smiles_language.stop_index]).to(self.device),
+            generate_len=generate_len,
+            search=search if search is not None else SamplingSearch())
+        return [[self.smiles_language.start_index] + m.cpu().detach().tolist() for m in molecule_iter]
 
     def reconstruct(self, smiles):
-        raise NotImplementedError('sampling-based generation is outside the training hot path (SURVEY §8f item 3)')
+        """Reference :133-139 (`smiles` is a packed token batch, as there)."""
+        mu, logvar = self.gru_vae.encode(smiles)
+        tokens = self.decode(mu)
+        rec_smils = [self.smiles_language.token_indexes_to_smiles(t) for t in tokens]
+        return rec_smils, mu, logvar
 
     def train_step(self, input_seq, decoder_seq, target_seq, eps=None):
         """Reference :141-169.  Returns (decoder_loss, mu, logvar, latent_z[1, B, Z]).

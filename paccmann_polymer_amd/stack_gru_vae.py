@@ -207,6 +207,65 @@ def _gemm(ta, tb, M, N, K, A, lda, Bm, ldb, C, ldc, bias=None, ws=None, wsb=0):
                                _C.p(bias), _C.p(ws), wsb, _C.stream()))
 
 
+def _seq_forward(tokens, batch_sizes, dims, h0, S0, emb, wc, bc, wsi, bsi, gru):
+    """Runs ppk_stackgru_seq_fwd; returns every buffer the backward (or the single-step API) needs."""
+    V, E, H, L, W, D, pad = dims
+    _C.require_gpu(tokens, h0, emb, wc, bc, wsi, bsi, *gru)
+    dev = emb.device
+    T = batch_sizes.numel()
+    B = int(batch_sizes[0])
+    NT = int(tokens.numel())
+    Hp = _round_up(H, 32)
+    ks = _round_up(W, 32)
+    ldcs = _round_up(3 + W, 32)
+    f32 = dict(dtype=torch.float32, device=dev)
+    w_ih = [gru[4 * l + 0] for l in range(L)]
+    w_hh = [gru[4 * l + 1] for l in range(L)]
+    b_ih = [gru[4 * l + 2] for l in range(L)]
+    b_hh = [gru[4 * l + 3] for l in range(L)]
+
+    # [3+W, Hp] stack heads (controls rows 0..2, then the stack input layer)
+    wcs = _pad_units(torch.cat([wc, wsi], dim=0), H, Hp, 1)
+    bcs = torch.cat([bc, bsi], dim=0).contiguous()
+    w_hh_p = [_pad_units(_pad_units(w, H, Hp, 0, 3), H, Hp, 1) for w in w_hh]
+    b_hh_p = [_pad_units(b, H, Hp, 0, 3) for b in b_hh]
+    w_ih_p = [None] + [_pad_units(_pad_units(w, H, Hp, 0, 3), H, Hp, 1) for w in w_ih[1:]]
+    b_ih_p = [None] + [_pad_units(b, H, Hp, 0, 3) for b in b_ih[1:]]
+    w0 = _pad_units(w_ih[0], H, Hp, 0, 3)                       # [3Hp, E + W]
+    b0 = _pad_units(b_ih[0], H, Hp, 0, 3)
+    w0e = w0[:, :E]                                             # view, row stride E + W
+    wx0s = torch.zeros(3 * Hp, ks, **f32)
+    wx0s[:, :W] = w0[:, E:E + W]
+    embc = emb.contiguous()
+    table = torch.empty(V, 3 * Hp, **f32)
+    _gemm(0, 1, V, 3 * Hp, E, embc, E, w0e, E + W, table, 3 * Hp, bias=b0)
+    h0p = _pad_units(h0, H, Hp, 2)
+    if S0 is not None:
+        S0 = S0.to(torch.float32).contiguous()
+        if tuple(S0.shape) != (B, D, W):
+            raise ValueError()
+
+    XS = torch.empty(NT, ks, **f32)
+    Hs = torch.empty(L, NT, Hp, **f32)
+    HP = torch.empty(L, NT, Hp, **f32)
+    gates = torch.empty(L, NT, 4 * Hp, **f32)
+    S = torch.empty(NT, D, W, **f32)
+    CS = torch.empty(NT, ldcs, **f32)
+    wsb = _lib.ppk_stackgru_seq_fwd_workspace_bytes(B, Hp, L, W)
+    ws = _ws(wsb, dev)
+    bs_host = batch_sizes.contiguous()
+    dummy = w_hh_p[0]
+    _C.check(_lib.ppk_stackgru_seq_fwd(
+        T, ctypes.c_void_p(bs_host.data_ptr()), B, NT, V, Hp, L, W, D,
+        _C.p(tokens), _C.p(table), _C.p(wx0s), ks,
+        _ptr_array([dummy] + w_ih_p[1:]), _ptr_array(w_hh_p),
+        _ptr_array([dummy] + b_ih_p[1:]), _ptr_array(b_hh_p), _C.p(wcs), _C.p(bcs), _C.p(h0p), _C.p(S0),
+        _C.p(XS), _C.p(Hs), _C.p(HP), _C.p(gates), _C.p(S), _C.p(CS), ldcs,
+        _C.p(ws), wsb, _C.stream()))
+    return dict(XS=XS, Hs=Hs, HP=HP, gates=gates, S=S, CS=CS, wcs=wcs, wx0s=wx0s, w_ih_p=w_ih_p, w_hh_p=w_hh_p,
+                embc=embc, w0=w0, bs_host=bs_host, dims=(V, E, H, Hp, L, W, D, T, B, NT, ks, ldcs), pad=pad)
+
+
 class _StackGRUSeq(torch.autograd.Function):
     """K1: the whole packed StackGRU sequence.  Returns the top layer's output of
     every step, [NT, H] in packed order.
@@ -221,65 +280,20 @@ class _StackGRUSeq(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, tokens, batch_sizes, dims, h0, emb, wc, bc, wsi, bsi, *gru):
-        V, E, H, L, W, D, pad = dims
-        _C.require_gpu(tokens, h0, emb, wc, bc, wsi, bsi, *gru)
-        dev = emb.device
-        T = batch_sizes.numel()
-        B = int(batch_sizes[0])
-        NT = int(tokens.numel())
-        Hp = _round_up(H, 32)
-        ks = _round_up(W, 32)
-        ldcs = _round_up(3 + W, 32)
-        f32 = dict(dtype=torch.float32, device=dev)
-        w_ih = [gru[4 * l + 0] for l in range(L)]
-        w_hh = [gru[4 * l + 1] for l in range(L)]
-        b_ih = [gru[4 * l + 2] for l in range(L)]
-        b_hh = [gru[4 * l + 3] for l in range(L)]
-
-        # [3+W, Hp] stack heads (controls rows 0..2, then the stack input layer)
-        wcs = _pad_units(torch.cat([wc, wsi], dim=0), H, Hp, 1)
-        bcs = torch.cat([bc, bsi], dim=0).contiguous()
-        w_hh_p = [_pad_units(_pad_units(w, H, Hp, 0, 3), H, Hp, 1) for w in w_hh]
-        b_hh_p = [_pad_units(b, H, Hp, 0, 3) for b in b_hh]
-        w_ih_p = [None] + [_pad_units(_pad_units(w, H, Hp, 0, 3), H, Hp, 1) for w in w_ih[1:]]
-        b_ih_p = [None] + [_pad_units(b, H, Hp, 0, 3) for b in b_ih[1:]]
-        w0 = _pad_units(w_ih[0], H, Hp, 0, 3)                       # [3Hp, E + W]
-        b0 = _pad_units(b_ih[0], H, Hp, 0, 3)
-        w0e = w0[:, :E]                                             # view, row stride E + W
-        wx0s = torch.zeros(3 * Hp, ks, **f32)
-        wx0s[:, :W] = w0[:, E:E + W]
-        embc = emb.contiguous()
-        table = torch.empty(V, 3 * Hp, **f32)
-        _gemm(0, 1, V, 3 * Hp, E, embc, E, w0e, E + W, table, 3 * Hp, bias=b0)
-        h0p = _pad_units(h0, H, Hp, 2)
-
-        XS = torch.empty(NT, ks, **f32)
-        Hs = torch.empty(L, NT, Hp, **f32)
-        HP = torch.empty(L, NT, Hp, **f32)
-        gates = torch.empty(L, NT, 4 * Hp, **f32)
-        S = torch.empty(NT, D, W, **f32)
-        CS = torch.empty(NT, ldcs, **f32)
-        wsb = _lib.ppk_stackgru_seq_fwd_workspace_bytes(B, Hp, L, W)
-        ws = _ws(wsb, dev)
-        bs_host = batch_sizes.contiguous()
-        dummy = w_hh_p[0]
-        _C.check(_lib.ppk_stackgru_seq_fwd(
-            T, ctypes.c_void_p(bs_host.data_ptr()), B, NT, V, Hp, L, W, D,
-            _C.p(tokens), _C.p(table), _C.p(wx0s), ks,
-            _ptr_array([dummy] + w_ih_p[1:]), _ptr_array(w_hh_p),
-            _ptr_array([dummy] + b_ih_p[1:]), _ptr_array(b_hh_p), _C.p(wcs), _C.p(bcs), _C.p(h0p),
-            _C.p(XS), _C.p(Hs), _C.p(HP), _C.p(gates), _C.p(S), _C.p(CS), ldcs,
-            _C.p(ws), wsb, _C.stream()))
+        r = _seq_forward(tokens, batch_sizes, dims, h0, None, emb, wc, bc, wsi, bsi, gru)
+        V, E, H, Hp, L, W, D, T, B, NT, ks, ldcs = r['dims']
+        f32 = dict(dtype=torch.float32, device=emb.device)
         # transposed copies for the backward's data-gradient GEMMs (k-contiguous operands)
         wcs_t = torch.zeros(Hp, ldcs, **f32)
-        wcs_t[:, :3 + W] = wcs.t()
-        w_ih_t = [wx0s[:, :W].t().contiguous()] + [w.t().contiguous() for w in w_ih_p[1:]]
-        w_hh_t = [w.t().contiguous() for w in w_hh_p]
-        ctx.save_for_backward(tokens, XS, Hs, HP, gates, S, CS, wcs_t, embc, w0, *w_ih_t, *w_hh_t)
-        ctx.bs_host = bs_host
-        ctx.dims = (V, E, H, Hp, L, W, D, T, B, NT, ks, ldcs)
-        ctx.padding_idx = -1 if pad is None else int(pad)
-        return _unpad_units(Hs[L - 1], H, Hp, 1)
+        wcs_t[:, :3 + W] = r['wcs'].t()
+        w_ih_t = [r['wx0s'][:, :W].t().contiguous()] + [w.t().contiguous() for w in r['w_ih_p'][1:]]
+        w_hh_t = [w.t().contiguous() for w in r['w_hh_p']]
+        ctx.save_for_backward(tokens, r['XS'], r['Hs'], r['HP'], r['gates'], r['S'], r['CS'], wcs_t, r['embc'], r['w0'],
+                              *w_ih_t, *w_hh_t)
+        ctx.bs_host = r['bs_host']
+        ctx.dims = r['dims']
+        ctx.padding_idx = -1 if r['pad'] is None else int(r['pad'])
+        return _unpad_units(r['Hs'][L - 1], H, Hp, 1)
 
     @staticmethod
     def backward(ctx, dHtop):
@@ -436,6 +450,31 @@ class StackGRU(nn.Module):
                                   *self._gru_params())
 
 
+    def init_state(self, batch_size: Optional[int] = None):
+        """Zero hidden state [L, B, H] and empty stack [B, D, W] (upstream `init_hidden` / `init_stack`)."""
+        B = int(batch_size if batch_size is not None else self.batch_size)
+        dev = self.embedding.weight.device
+        return (torch.zeros(self.n_layers, B, self.rnn_cell_size, dtype=torch.float32, device=dev),
+                torch.zeros(B, self.stack_depth, self.stack_width, dtype=torch.float32, device=dev))
+
+    def forward(self, token, hidden, stack):
+        """One StackGRU step (the call of paccmann_chemistry's generation loop that the
+        reference reaches through paccmann_encoder.py:115-131): token [1, B] or [B] int64, hidden [L, B, H],
+        stack [B, D, W] -> (out [1, B, H], hidden, stack).  Inference only (no autograd): training goes
+        through the packed-sequence path."""
+        tok = token.reshape(-1).to(self.embedding.weight.device, torch.int64).contiguous()
+        B = int(tok.numel())
+        if hidden.shape != (self.n_layers, B, self.rnn_cell_size) or stack.shape != (B, self.stack_depth, self.stack_width):
+            raise ValueError()
+        with torch.no_grad():
+            r = _seq_forward(tok, torch.tensor([B], dtype=torch.int64), self._dims(), hidden.to(torch.float32), stack,
+                             self.embedding.weight, self.stack_controls_layer.weight, self.stack_controls_layer.bias,
+                             self.stack_input_layer.weight, self.stack_input_layer.bias, self._gru_params())
+            H = self.rnn_cell_size
+            new_hidden = r['Hs'][:, :, :H].contiguous()
+            return new_hidden[-1].unsqueeze(0), new_hidden, r['S']
+
+
 def _require_packed(x):
     if not isinstance(x, PackedSequence):
         raise TypeError('the HIP path takes PackedSequence batches (batch_mode="packed")')
@@ -478,7 +517,6 @@ class StackGRUEncoder(StackGRU):
         logvar = linear(hfin, self.hidden_to_logvar.weight, self.hidden_to_logvar.bias)
         return mu, logvar
 
-    forward = encoder_train_step
 
 
 class StackGRUDecoder(StackGRU):
@@ -515,7 +553,25 @@ class StackGRUDecoder(StackGRU):
         tgt = packed_tgt.data.reshape(-1).to(device=dev, dtype=torch.int64).contiguous()
         return _CrossEntropy.apply(logits, tgt, 0)
 
-    forward = decoder_train_step
+
+
+class GreedySearch:
+    """argmax of the logits (stand-in for paccmann_chemistry.utils.search.GreedySearch)."""
+
+    def step(self, logits):
+        return logits.argmax(dim=-1)
+
+
+class SamplingSearch:
+    """multinomial sample of softmax(logits / temperature) with the torch global RNG (stand-in for
+    paccmann_chemistry.utils.search.SamplingSearch, the default of paccmann_encoder.py:115)."""
+
+    def __init__(self, temperature: float = 1.0):
+        self.temperature = float(temperature)
+
+    def step(self, logits):
+        probs = torch.softmax(logits / self.temperature, dim=-1)
+        return torch.multinomial(probs, 1).squeeze(-1)
 
 
 class TeacherVAE(nn.Module):
@@ -550,6 +606,33 @@ class TeacherVAE(nn.Module):
         mu, logvar = self.encode(input_seq)
         z = self.reparameterize(mu, logvar, eps).unsqueeze(0)
         return self.decode(z, decoder_seq, target_seq), mu, logvar
+
+    def generate(self, latent_z, prime_input, end_token, generate_len: int = 100, search=None):
+        """Token generation from latent codes (the upstream `TeacherVAE.generate` call of
+        paccmann_encoder.py:119-127; its body is not in the reference tree, so this is BUILD-DEFINED and
+        parity-unpinned): hidden = latent_to_hidden(z) on every layer, empty stack, feed `prime_input`, then
+        `generate_len` single steps, the next token chosen by `search` from the logits.  Yields one int64
+        tensor per sample: the generated tokens up to and including the first `end_token`."""
+        dec = self.decoder
+        search = search if search is not None else SamplingSearch()
+        with torch.no_grad():
+            z = latent_z.reshape(-1, latent_z.shape[-1]).to(dec.embedding.weight.device, torch.float32)
+            B = z.shape[0]
+            h = linear(z, dec.latent_to_hidden.weight, dec.latent_to_hidden.bias)
+            hidden = h.unsqueeze(0).repeat(dec.n_layers, 1, 1).contiguous()
+            _, stack = dec.init_state(B)
+            token = prime_input.reshape(-1)[:1].to(z.device, torch.int64).repeat(B)
+            end = int(end_token.reshape(-1)[0])
+            out_tokens = []
+            for _ in range(int(generate_len)):
+                out, hidden, stack = dec(token, hidden, stack)
+                logits = linear(out.squeeze(0).contiguous(), dec.output_layer.weight, dec.output_layer.bias)
+                token = search.step(logits).reshape(-1).to(torch.int64)
+                out_tokens.append(token)
+            tokens = torch.stack(out_tokens, dim=1).cpu() if out_tokens else torch.zeros(B, 0, dtype=torch.int64)
+        for row in tokens:
+            hit = (row == end).nonzero()
+            yield row[:int(hit[0]) + 1] if hit.numel() else row
 
     def save(self, path, *args, **kwargs):
         torch.save(self.state_dict(), path, *args, **kwargs)

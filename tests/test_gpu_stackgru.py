@@ -195,3 +195,41 @@ def test_reparam_kl_kernel_matches_reference_twin_golden():
         assert rel(z, torch.tensor(g['z'])) <= 1e-6
         assert abs(float(kl) - float(g['kld'])) <= 1e-5 * abs(float(g['kld']))
         assert rel(mu.grad, torch.tensor(g['dmu'])) <= 1e-5 and rel(logvar.grad, torch.tensor(g['dlogvar'])) <= 1e-5
+
+
+def test_full_size_batch_equals_weighted_halves():
+    """Size-independent property at BASELINE config 1b (2048 sequences, ragged 20..100 tokens, the full
+    model): the token-mean decoder loss and the KL of the whole batch, and every parameter gradient, equal
+    the token-weighted combination of the two half batches.  The halves run through different launch
+    shapes (1024-row tiles, other split-K slab counts, other tile families on the tails) than the whole."""
+    rng = np.random.default_rng(77)
+    _, gpu = build_pair(FULL, 77, torch.float32)
+    B = 2048
+    seqs = make_batch(rng, B, FULL['vocab_size'], 20, 100)
+    eps = torch.tensor(rng.standard_normal((B, FULL['latent_dim'])), dtype=torch.float32).cuda()
+    n_tok = lambda idx: sum(len(seqs[i]) for i in idx) - len(idx)        # targets that are not padding
+    c = 1e-3
+
+    def run(idx, kl_weight):
+        gpu.zero_grad(set_to_none=True)
+        enc, dec, tgt = prep([seqs[i] for i in idx])
+        mu, lv = gpu.encode(enc)
+        z = gpu.reparameterize(mu, lv, eps[idx]).unsqueeze(0)
+        loss = gpu.decode(z, dec, tgt)
+        (loss + kl_weight * gpu.last_kl).backward()
+        return float(loss.detach()), float(gpu.last_kl.detach()), {k: p.grad.detach().double().clone() for k, p in gpu.named_parameters()}
+
+    everything = list(range(B))
+    parts = [list(range(0, B // 2)), list(range(B // 2, B))]
+    w = [n_tok(p) / n_tok(everything) for p in parts]
+    whole = run(everything, c)
+    # w_h * (loss_h + (c / w_h) * kl_h) summed over the halves is the whole objective
+    halves = [run(p, c / wh) for p, wh in zip(parts, w)]
+    assert abs(w[0] * halves[0][0] + w[1] * halves[1][0] - whole[0]) <= 1e-5 * abs(whole[0])
+    assert abs(halves[0][1] + halves[1][1] - whole[1]) <= 1e-5 * abs(whole[1])
+    for name, g in whole[2].items():
+        want = w[0] * halves[0][2][name] + w[1] * halves[1][2][name]
+        if float(g.norm()) < 1e-12:
+            assert float(want.norm()) < 1e-9, name
+            continue
+        assert rel(want, g) <= 1e-4, (name, rel(want, g))

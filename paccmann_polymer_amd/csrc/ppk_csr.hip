@@ -13,7 +13,12 @@
 // CSR build without a global sort: integer histogram -> exclusive scan -> atomic
 // fill (arbitrary order inside a row) -> per-row sort by edge id (unique keys, so the
 // final order is deterministic).  Short rows are sorted by one lane each, long rows
-// (hubs of power-law relation graphs) by a workgroup bitonic sort in LDS.
+// (hubs of power-law relation graphs) by a workgroup bitonic sort in LDS; rows beyond
+// one LDS image (> 8192 entries) are sorted in 8192-entry chunks and the chunks merged by
+// grid-wide rank-merge passes (every entry finds its place in the paired run by binary
+// search; keys are unique), ping-ponging between `eid` and the not yet written `col`.
+// k_finish and the SpMM give such rows to many lanes as well (k_finish_long, k_spmm_long):
+// a hub with 5.5e5 entries took 170 s to build with one workgroup's transposition sort.
 #include "ppk_common.h"
 #include "ppk_kernels.h"
 
@@ -24,6 +29,8 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int SCAN_BLOCK = 1024;     // elements per scan block (256 threads x 4)
 constexpr int SHORT_ROW = 16;
 constexpr int LDS_SORT_MAX = 8192;
+constexpr int FINISH_LONG = 64;      // rows beyond this are finished by k_finish_long
+constexpr int SPMM_LONG = 1024;      // rows beyond this are reduced by a whole workgroup (k_spmm_long)
 
 inline unsigned grid_for(long long work, unsigned cap = 8192)
 {
@@ -160,45 +167,87 @@ __global__ __launch_bounds__(256) void k_sort_short(const long long* __restrict_
             if (k < len) eid[b + k] = v[k];
     }
 }
-// long rows: one workgroup per row, bitonic sort (LDS when it fits, global otherwise)
+// bitonic sort of a[0..len) (len <= LDS_SORT_MAX) through the LDS image `buf`, by the whole workgroup
+__device__ inline void lds_sort(long long* __restrict__ buf, long long* __restrict__ a, int len)
+{
+    int n2 = 1;
+    while (n2 < len) n2 <<= 1;
+    for (int k = threadIdx.x; k < n2; k += 256) buf[k] = k < len ? a[k] : 0x7fffffffffffffffLL;
+    __syncthreads();
+    for (int size = 2; size <= n2; size <<= 1)
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            for (int k = threadIdx.x; k < n2 / 2; k += 256) {
+                const int lo = 2 * k - (k & (stride - 1));
+                const int hi = lo + stride;
+                const bool up = (lo & size) == 0;
+                const long long x = buf[lo], y = buf[hi];
+                if ((x > y) == up) { buf[lo] = y; buf[hi] = x; }
+            }
+            __syncthreads();
+        }
+    for (int k = threadIdx.x; k < len; k += 256) a[k] = buf[k];
+    __syncthreads();
+}
+// long rows: one workgroup per row, bitonic sort in LDS.  Rows beyond one LDS image are sorted chunk by chunk
+// and queued for the merge passes.
 __global__ __launch_bounds__(256) void k_sort_long(const long long* __restrict__ rowptr, long long* __restrict__ eid,
-                                                   const int* __restrict__ long_rows, const int* __restrict__ n_long)
+                                                   const int* __restrict__ long_rows, const int* __restrict__ n_long,
+                                                   int* __restrict__ vlong_rows, int* __restrict__ n_vlong)
 {
     __shared__ long long buf[LDS_SORT_MAX];
     const int nl = *n_long;
     for (int q = blockIdx.x; q < nl; q += gridDim.x) {
         const long long i = long_rows[q];
         const long long b = rowptr[i];
-        const int len = (int)(rowptr[i + 1] - b);
-        if (len <= LDS_SORT_MAX) {
-            int n2 = 1;
-            while (n2 < len) n2 <<= 1;
-            for (int k = threadIdx.x; k < n2; k += 256) buf[k] = k < len ? eid[b + k] : 0x7fffffffffffffffLL;
-            __syncthreads();
-            for (int size = 2; size <= n2; size <<= 1)
-                for (int stride = size >> 1; stride > 0; stride >>= 1) {
-                    for (int k = threadIdx.x; k < n2 / 2; k += 256) {
-                        const int lo = 2 * k - (k & (stride - 1));
-                        const int hi = lo + stride;
-                        const bool up = (lo & size) == 0;
-                        const long long a = buf[lo], c = buf[hi];
-                        if ((a > c) == up) { buf[lo] = c; buf[hi] = a; }
-                    }
-                    __syncthreads();
-                }
-            for (int k = threadIdx.x; k < len; k += 256) eid[b + k] = buf[k];
-            __syncthreads();
-        } else {
-            // very long row: odd-even transposition sort in global memory by this workgroup (rare; O(len^2 / 256))
-            long long* a = eid + b;
-            for (int pass = 0; pass < len; ++pass) {
-                for (int k = (pass & 1) + 2 * threadIdx.x; k + 1 < len; k += 512) {
-                    const long long x = a[k], y = a[k + 1];
-                    if (x > y) { a[k] = y; a[k + 1] = x; }
-                }
-                __syncthreads();
+        const long long len = rowptr[i + 1] - b;
+        for (long long c0 = 0; c0 < len; c0 += LDS_SORT_MAX)
+            lds_sort(buf, eid + b + c0, (int)(len - c0 < LDS_SORT_MAX ? len - c0 : LDS_SORT_MAX));
+        if (len > LDS_SORT_MAX && threadIdx.x == 0) vlong_rows[atomicAdd(n_vlong, 1)] = (int)i;
+    }
+}
+// merge pass p over the queued rows: sorted runs of LDS_SORT_MAX << p entries are merged in pairs.  Every entry
+// computes its own output position: its index in its run plus the number of smaller keys in the partner run.
+// Even passes read `eid` and write `scratch`, odd passes the other way; a row whose runs already cover it is skipped.
+__global__ __launch_bounds__(256) void k_merge_pass(const long long* __restrict__ rowptr, long long* __restrict__ eid,
+                                                    long long* __restrict__ scratch, const int* __restrict__ vlong_rows,
+                                                    const int* __restrict__ n_vlong, int p)
+{
+    const int nv = *n_vlong;
+    const long long run = (long long)LDS_SORT_MAX << p;
+    for (int q = blockIdx.y; q < nv; q += gridDim.y) {
+        const long long i = vlong_rows[q];
+        const long long b = rowptr[i], len = rowptr[i + 1] - b;
+        if (run >= len) continue;
+        const long long* __restrict__ s = (p & 1) ? scratch + b : eid + b;
+        long long* __restrict__ d = (p & 1) ? eid + b : scratch + b;
+        for (long long k = (long long)blockIdx.x * 256 + threadIdx.x; k < len; k += (long long)gridDim.x * 256) {
+            const long long v = s[k];
+            const long long base = k / (2 * run) * (2 * run), mid = base + run;
+            if (mid >= len) { d[k] = v; continue; }                 // a run without a partner is carried over
+            const long long end = base + 2 * run < len ? base + 2 * run : len;
+            long long lo = k < mid ? mid : base, hi = k < mid ? end : mid;
+            const long long other0 = lo;
+            while (lo < hi) {
+                const long long m = (lo + hi) >> 1;
+                if (s[m] < v) lo = m + 1; else hi = m;
             }
+            d[base + (k < mid ? k - base : k - mid) + (lo - other0)] = v;
         }
+    }
+}
+// rows that went through an odd number of passes have their sorted entries in `scratch`
+__global__ __launch_bounds__(256) void k_merge_finish(const long long* __restrict__ rowptr, long long* __restrict__ eid,
+                                                      const long long* __restrict__ scratch, const int* __restrict__ vlong_rows,
+                                                      const int* __restrict__ n_vlong)
+{
+    const int nv = *n_vlong;
+    for (int q = blockIdx.y; q < nv; q += gridDim.y) {
+        const long long i = vlong_rows[q];
+        const long long b = rowptr[i], len = rowptr[i + 1] - b;
+        int passes = 0;
+        while (((long long)LDS_SORT_MAX << passes) < len) ++passes;
+        if (!(passes & 1)) continue;
+        for (long long k = (long long)blockIdx.x * 256 + threadIdx.x; k < len; k += (long long)gridDim.x * 256) eid[b + k] = scratch[b + k];
     }
 }
 
@@ -211,8 +260,34 @@ __global__ __launch_bounds__(256) void k_finish(const int64_t* __restrict__ src,
 {
     // one thread per row walks its entries (rows are short on average); grid-stride
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < N; i += (long long)gridDim.x * 256) {
+        if (rowptr[i + 1] - rowptr[i] > FINISH_LONG) continue;          // k_finish_long
         const float di = normalize ? rsqrtf((float)(deg_cnt[i] + deg_extra)) : 1.0f;
         for (long long j = rowptr[i]; j < rowptr[i + 1]; ++j) {
+            const long long e = eid[j];
+            const long long s = e < E ? src[e] : e - E;
+            col[j] = s;
+            float w = (e < E && edge_weight) ? edge_weight[e] : 1.0f;
+            if (normalize) w *= di * rsqrtf((float)(deg_cnt[s] + deg_extra));
+            val[j] = w;
+        }
+    }
+}
+
+// the same for rows beyond FINISH_LONG entries (taken from the long-row queue): blockIdx.y walks the rows,
+// blockIdx.x and the lanes walk the entries
+__global__ __launch_bounds__(256) void k_finish_long(const int64_t* __restrict__ src, long long E,
+                                                     const long long* __restrict__ rowptr, const long long* __restrict__ eid,
+                                                     const int* __restrict__ deg_cnt, int deg_extra, int normalize,
+                                                     const float* __restrict__ edge_weight, const int* __restrict__ long_rows,
+                                                     const int* __restrict__ n_long, long long* __restrict__ col, float* __restrict__ val)
+{
+    const int nl = *n_long;
+    for (int q = blockIdx.y; q < nl; q += gridDim.y) {
+        const long long i = long_rows[q];
+        const long long b = rowptr[i], e1 = rowptr[i + 1];
+        if (e1 - b <= FINISH_LONG) continue;
+        const float di = normalize ? rsqrtf((float)(deg_cnt[i] + deg_extra)) : 1.0f;
+        for (long long j = b + (long long)blockIdx.x * 256 + threadIdx.x; j < e1; j += (long long)gridDim.x * 256) {
             const long long e = eid[j];
             const long long s = e < E ? src[e] : e - E;
             col[j] = s;
@@ -234,6 +309,7 @@ __global__ __launch_bounds__(256) void k_spmm(const long long* __restrict__ rowp
     const long long nwaves = (long long)gridDim.x * 4;
     for (long long i = wave_global; i < N; i += nwaves) {
         const long long b = rowptr[i], e = rowptr[i + 1];
+        if (e - b > SPMM_LONG) continue;                                // k_spmm_long
         for (int f0 = lane * VEC; f0 < F; f0 += 64 * VEC) {
             if constexpr (VEC == 4) {
                 f32x4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -254,6 +330,75 @@ __global__ __launch_bounds__(256) void k_spmm(const long long* __restrict__ rowp
                 out[i * ldo + f0] = acc;
             }
         }
+    }
+}
+
+// Rows beyond SPMM_LONG entries: each workgroup (16 waves) scans its stripe of rowptr, and reduces every long row it
+// finds with all its waves: wave w takes the w-th contiguous sixteenth of the row, four gathers in flight, and the
+// sixteen partial sums are added in wave order (a fixed association: bitwise reproducible, but not the
+// entry-by-entry order of the short rows).
+template <int VEC>
+__global__ __launch_bounds__(1024) void k_spmm_long(const long long* __restrict__ rowptr, const long long* __restrict__ col,
+                                                    const float* __restrict__ val, const float* __restrict__ x, long long ldx,
+                                                    long long N, int F, float* __restrict__ out, long long ldo)
+{
+    __shared__ int list[1024];
+    __shared__ int nlist;
+    __shared__ float part[16][64 * VEC];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long long per = (N + gridDim.x - 1) / gridDim.x;
+    const long long r_begin = per * blockIdx.x, r_end = r_begin + per < N ? r_begin + per : N;
+    for (long long r0 = r_begin; r0 < r_end; r0 += 1024) {
+        const long long i = r0 + threadIdx.x;
+        const bool is_long = i < r_end && rowptr[i + 1] - rowptr[i] > SPMM_LONG;
+        if (!__syncthreads_or(is_long)) continue;
+        if (threadIdx.x == 0) nlist = 0;
+        __syncthreads();
+        if (is_long) list[atomicAdd(&nlist, 1)] = (int)(i - r0);
+        __syncthreads();
+        const int n = nlist;
+        for (int q = 0; q < n; ++q) {
+            const long long row = r0 + list[q];
+            const long long b = rowptr[row], len = rowptr[row + 1] - b;
+            const long long j0 = b + len * wave / 16, j1 = b + len * (wave + 1) / 16;
+            for (int f0 = 0; f0 < F; f0 += 64 * VEC) {
+                const int f = f0 + lane * VEC;
+                if constexpr (VEC == 4) {
+                    f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0, a2 = a0, a3 = a0;
+                    if (f < F) {
+                        long long j = j0;
+                        for (; j + 3 < j1; j += 4) {
+                            const f32x4 v0 = *(const f32x4*)(x + col[j] * ldx + f);
+                            const f32x4 v1 = *(const f32x4*)(x + col[j + 1] * ldx + f);
+                            const f32x4 v2 = *(const f32x4*)(x + col[j + 2] * ldx + f);
+                            const f32x4 v3 = *(const f32x4*)(x + col[j + 3] * ldx + f);
+                            a0 += val[j] * v0; a1 += val[j + 1] * v1; a2 += val[j + 2] * v2; a3 += val[j + 3] * v3;
+                        }
+                        for (; j < j1; ++j) a0 += val[j] * *(const f32x4*)(x + col[j] * ldx + f);
+                    }
+                    *(f32x4*)&part[wave][lane * 4] = (a0 + a1) + (a2 + a3);
+                } else {
+                    float a0 = 0.f;
+                    if (f < F)
+                        for (long long j = j0; j < j1; ++j) a0 = fmaf(val[j], x[col[j] * ldx + f], a0);
+                    part[wave][lane] = a0;
+                }
+                __syncthreads();
+                if (wave == 0 && f < F) {
+                    if constexpr (VEC == 4) {
+                        f32x4 t = *(const f32x4*)&part[0][lane * 4];
+                        for (int w = 1; w < 16; ++w) t += *(const f32x4*)&part[w][lane * 4];
+                        *(f32x4*)(out + row * ldo + f) = t;
+                    } else {
+                        float t = part[0][lane];
+                        for (int w = 1; w < 16; ++w) t += part[w][lane];
+                        out[row * ldo + f] = t;
+                    }
+                }
+                __syncthreads();
+            }
+        }
+        __syncthreads();
     }
 }
 
@@ -327,11 +472,28 @@ int ppk_csr_build(const int64_t* src, const int64_t* dst, int64_t E, int64_t N, 
     PPK_CHECK_LAUNCH("k_fill");
     k_sort_short<<<dim3(grid_for(N)), dim3(256), 0, stream>>>((const long long*)rowptr, N, (long long*)eid, w.long_rows, w.n_long);
     PPK_CHECK_LAUNCH("k_sort_short");
-    k_sort_long<<<dim3(512), dim3(256), 0, stream>>>((const long long*)rowptr, (long long*)eid, w.long_rows, w.n_long);
+    // the fill is over: `cursor` now queues the rows beyond one LDS image, counted in n_long[1]; `col` is not
+    // written before k_finish and serves as the merge passes' second buffer
+    int* vlong_rows = w.cursor;
+    int* n_vlong = w.n_long + 1;
+    k_sort_long<<<dim3(512), dim3(256), 0, stream>>>((const long long*)rowptr, (long long*)eid, w.long_rows, w.n_long, vlong_rows, n_vlong);
     PPK_CHECK_LAUNCH("k_sort_long");
+    int passes = 0;                                   // a row holds at most E + 1 entries
+    while (((long long)LDS_SORT_MAX << passes) < E + 1) ++passes;
+    for (int p = 0; p < passes; ++p) {
+        k_merge_pass<<<dim3(128, 16), dim3(256), 0, stream>>>((const long long*)rowptr, (long long*)eid, (long long*)col, vlong_rows, n_vlong, p);
+        PPK_CHECK_LAUNCH("k_merge_pass");
+    }
+    if (passes) {
+        k_merge_finish<<<dim3(128, 16), dim3(256), 0, stream>>>((const long long*)rowptr, (long long*)eid, (const long long*)col, vlong_rows, n_vlong);
+        PPK_CHECK_LAUNCH("k_merge_finish");
+    }
     k_finish<<<dim3(grid_for(N)), dim3(256), 0, stream>>>(src, E, N, (const long long*)rowptr, (const long long*)eid, w.cnt,
                                                           add_self_loops ? 1 : 0, normalize, edge_weight, (long long*)col, val);
     PPK_CHECK_LAUNCH("k_finish");
+    k_finish_long<<<dim3(8, 256), dim3(256), 0, stream>>>(src, E, (const long long*)rowptr, (const long long*)eid, w.cnt, add_self_loops ? 1 : 0,
+                                                          normalize, edge_weight, w.long_rows, w.n_long, (long long*)col, val);
+    PPK_CHECK_LAUNCH("k_finish_long");
     PPK_HIP(hipMemcpyAsync(status, w.bad, sizeof(int), hipMemcpyDeviceToDevice, stream));
     return PPK_OK;
 }
@@ -350,6 +512,9 @@ int ppk_spmm_csr(const int64_t* rowptr, const int64_t* col, const float* val, in
     if (vec) k_spmm<4><<<dim3(nb), dim3(256), 0, stream>>>((const long long*)rowptr, (const long long*)col, val, x, ldx, N, (int)F, out, ldo);
     else     k_spmm<1><<<dim3(nb), dim3(256), 0, stream>>>((const long long*)rowptr, (const long long*)col, val, x, ldx, N, (int)F, out, ldo);
     PPK_CHECK_LAUNCH("k_spmm");
+    if (vec) k_spmm_long<4><<<dim3(512), dim3(1024), 0, stream>>>((const long long*)rowptr, (const long long*)col, val, x, ldx, N, (int)F, out, ldo);
+    else     k_spmm_long<1><<<dim3(512), dim3(1024), 0, stream>>>((const long long*)rowptr, (const long long*)col, val, x, ldx, N, (int)F, out, ldo);
+    PPK_CHECK_LAUNCH("k_spmm_long");
     return PPK_OK;
 }
 

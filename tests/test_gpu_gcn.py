@@ -24,7 +24,8 @@ def random_graph(rng, n, e, hubs=0, self_loops=True):
     return torch.tensor(np.stack([src, dst]), dtype=torch.int64)
 
 
-@pytest.mark.parametrize('n,e,hubs', [(9, 8, 0), (50, 400, 0), (1000, 30000, 2), (5000, 200000, 1), (7, 0, 0), (3000, 2999, 0)])
+@pytest.mark.parametrize('n,e,hubs', [(9, 8, 0), (50, 400, 0), (1000, 30000, 2), (5000, 200000, 1), (7, 0, 0), (3000, 2999, 0),
+                                      (3000, 40000, 1), (900, 100000, 2), (50, 120000, 1)])     # rows beyond one LDS sort image: chunk sort + merge passes
 def test_csr_build_bit_exact(n, e, hubs):
     from oracle import gcn_ref as R
     from paccmann_polymer_amd.gcn import CSRGraph
@@ -61,7 +62,8 @@ def test_reference_example_edge_index():
     assert rel(out, ref) <= 1e-6
 
 
-@pytest.mark.parametrize('n,e,fin,fout', [(200, 1500, 256, 512), (64, 300, 30, 7), (4000, 50000, 64, 64)])
+@pytest.mark.parametrize('n,e,fin,fout', [(200, 1500, 256, 512), (64, 300, 30, 7), (4000, 50000, 64, 64), (500, 9000, 30, 7),
+                                            (300, 20000, 320, 16)])      # hub rows: k_spmm_long, scalar and vector
 def test_gcnconv_fwd_bwd(n, e, fin, fout):
     from oracle import gcn_ref as R
     from paccmann_polymer_amd.gcn import GCNConv
@@ -128,3 +130,39 @@ def test_bad_edge_index_reported():
     ei = torch.tensor([[0, 1], [1, 7]]).cuda()
     with pytest.raises(IndexError):
         CSRGraph(ei, 3, check=True)
+
+
+def test_full_size_csr_and_spmm_vs_torch_on_device():
+    """K6 + K7 at BASELINE configs[2] size (2.4 M nodes, 5 M directed edges, F = 256).  The CPU oracle would
+    take minutes here, so the same statements (stable sort of the augmented edge list by target; fp64
+    index_add in edge order) are evaluated with torch on the device: integers bit-exact, sums to 1e-6."""
+    from paccmann_polymer_amd import gcn
+    rng = np.random.default_rng(9)
+    N, E, F = 2_400_000, 5_000_000, 256
+    ei = random_graph(rng, N, E, hubs=3).cuda()
+    g = gcn.CSRGraph(ei, N, check=True)
+    rowptr, col, eid, val, _ = g.fwd
+    keep = ei[0] != ei[1]
+    loops = torch.arange(N, device='cuda')
+    src = torch.cat([ei[0][keep], loops])
+    dst = torch.cat([ei[1][keep], loops])
+    ids = torch.cat([torch.arange(E, device='cuda')[keep], E + loops])
+    nnz = int(src.numel())
+    assert int(rowptr[-1]) == nnz
+    deg = torch.bincount(dst, minlength=N)
+    assert torch.equal(rowptr[1:].long(), torch.cumsum(deg, 0))
+    _, order = torch.sort(dst, stable=True)
+    assert torch.equal(col[:nnz].long(), src[order])
+    assert torch.equal(eid[:nnz].long(), ids[order])
+    dinv = deg.double().pow(-0.5)
+    norm = dinv[src] * dinv[dst]
+    assert torch.allclose(val[:nnz].double(), norm[order], rtol=1e-6, atol=0)
+    x = torch.randn(N, F, device='cuda')
+    y = gcn._spmm(g.fwd, x, g.nnz_cap)
+    ref = torch.zeros(N, F, dtype=torch.float64, device='cuda').index_add_(0, dst, norm[:, None] * x.double()[src])
+    assert rel(y, ref) <= 1e-6
+    del ref
+    yt = gcn._spmm(g.rev, x, g.nnz_cap)
+    ref = torch.zeros(N, F, dtype=torch.float64, device='cuda').index_add_(0, src, norm[:, None] * x.double()[dst])
+    assert rel(yt, ref) <= 1e-6
+    assert torch.equal(y, gcn._spmm(g.fwd, x, g.nnz_cap))

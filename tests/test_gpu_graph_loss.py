@@ -125,3 +125,49 @@ def test_errors():
         P.graph_loss(z, torch.zeros(5, 5))
     with pytest.raises(ValueError):
         P.graph_loss_segmented(z, [np.zeros((2, 2)), np.zeros((3, 3))], [2, 3])
+
+
+def _torch_fp64_graph_loss(z, G):
+    """The reference's two rasters (graph_constrained_loss.py:25-67: column raster (i, j, r >= i, r != j),
+    row raster (i, j, c >= j) whose delta compares G with D) as plain torch fp64 on the device, one anchor
+    row per iteration so the working set stays [N, N]; gradient through cdist and the max normaliser."""
+    n = z.shape[0]
+    z64 = z.double().requires_grad_(True)
+    D = torch.cdist(z64, z64, compute_mode='donot_use_mm_for_euclid_dist')
+    Dl = D.detach().clone().requires_grad_(True)
+
+    def f(delta, a, b):
+        return torch.where(delta == 0, (a - b) ** 2, torch.where(delta > 0, (b - a).clamp_min(0), (a - b).clamp_min(0)))
+
+    S = 0.0
+    for i in range(n - 1):
+        a = Dl[i, i + 1:]                                     # D[i, j], j = i+1 .. n-1
+        g_ij = G[i, i + 1:]
+        Dc = Dl[i:, i + 1:]                                   # D[r, j], r = i .. n-1
+        t = f(g_ij[None, :] - G[i:, i + 1:], a[None, :], Dc)
+        col = t.sum() - t[1:].diagonal().sum()                # r == j is skipped
+        t2 = f(g_ij[:, None] - a.detach()[None, :], a[:, None], a[None, :])       # [j, c]
+        s = col + torch.triu(t2).sum()                        # c >= j
+        s.backward()
+        S += float(s.detach())
+    mx = D.max()
+    ((D * Dl.grad).sum() / mx.detach() - S / mx.detach() ** 2 * mx).backward()
+    return S / float(mx.detach()), z64.grad
+
+
+def test_dense_full_size_vs_torch_fp64_on_device():
+    """K4 at BASELINE size (one dense graph, N = 2048, Z = 256; the tiled-distance path and the fp32-held G
+    fast path) against the fp64 torch statement of the reference loops, evaluated on the same device."""
+    from scipy.sparse import coo_matrix
+    from scipy.sparse.csgraph import shortest_path
+    n, zd = 2048, 256
+    rng = np.random.default_rng(5)
+    z = (rng.standard_normal((n, zd)) * 1.5 / np.sqrt(zd)).astype(np.float32)
+    e = rng.integers(0, n, size=(2, 3 * n))
+    A = coo_matrix((np.ones(e.shape[1]), (e[0], e[1])), shape=(n, n))
+    G = shortest_path(A, directed=False, unweighted=True)
+    G[np.isinf(G)] = 0
+    loss, dz = run_gpu(z, G)
+    ref, dref = _torch_fp64_graph_loss(torch.tensor(z).cuda(), torch.tensor(G).cuda())
+    assert abs(loss - ref) <= 1e-5 * abs(ref), (loss, ref)
+    assert rel(dz, dref.cpu().numpy()) <= 1e-4

@@ -68,3 +68,54 @@ def test_sharded_two_ranks_match_single():
                          env=env, capture_output=True, text=True, timeout=240)
     assert out.returncode == 0, out.stdout + out.stderr
     assert 'SPARSE_DP_OK' in out.stdout
+
+
+def test_full_size_anchor_ranges_sum_to_whole():
+    """K5 at BASELINE configs[3] size (1 M nodes, ~10 M undirected power-law edges, Z = 256): the eight
+    work-balanced anchor ranges, evaluated one after the other on this GPU with the two scalar exchanges
+    (MAX of the edge distances, SUM of the terms) done by hand, give the whole-graph loss and gradient."""
+    from paccmann_polymer_amd import _C
+    from paccmann_polymer_amd.graph_loss_sparse import SparseRelationGraph, graph_loss_sparse
+    lib = _C.lib
+    rng = np.random.default_rng(1)
+    N, Z, m = 1_000_000, 256, 10
+    src = np.repeat(np.arange(1, N, dtype=np.int64), m)
+    dst = (src * rng.random(src.size) ** 1.5).astype(np.int64)
+    key = np.unique(np.minimum(src, dst) * N + np.maximum(src, dst))
+    key = key[(key // N) != (key % N)]
+    und = np.stack([key // N, key % N])
+    E = und.shape[1]
+    graph = SparseRelationGraph(torch.tensor(und).cuda(), torch.tensor(rng.integers(1, 4, size=E).astype(np.float32)).cuda(), N)
+    z = (torch.randn(N, Z, device='cuda') * 1.5 / 16).requires_grad_(True)
+    whole = graph_loss_sparse(z, graph)
+    whole.backward()
+
+    starts = graph.anchor_ranges(8)
+    assert starts[0] == 0 and starts[-1] == N and all(a <= b for a, b in zip(starts, starts[1:]))
+    wsb = lib.ppk_graphreg_sparse_workspace_bytes(N, E, Z)
+    st = _C.stream()
+    zc = z.detach().contiguous()
+    wss = [torch.empty(wsb, dtype=torch.uint8, device='cuda') for _ in range(8)]
+    view = lambda ws, off, nbytes, dt: ws[off:off + nbytes].view(dt)
+    for r, ws in enumerate(wss):
+        _C.check(lib.ppk_graphreg_sparse_dist(_C.p(zc), zc.stride(0), N, Z, _C.p(graph.g), E, _C.p(graph.rowptr),
+                                              _C.p(graph.col), _C.p(graph.eid), starts[r], starts[r + 1], _C.p(ws), wsb, st))
+    moff = lib.ppk_graphreg_sparse_max_ptr(_C.p(wss[0]), N, E) - wss[0].data_ptr()
+    soff = lib.ppk_graphreg_sparse_sum_ptr(_C.p(wss[0]), N, E) - wss[0].data_ptr()
+    mx = torch.stack([view(ws, moff, 4, torch.float32) for ws in wss]).max()
+    for r, ws in enumerate(wss):
+        view(ws, moff, 4, torch.float32).fill_(mx)
+        _C.check(lib.ppk_graphreg_sparse_terms(N, E, _C.p(graph.rowptr), _C.p(graph.col), starts[r], starts[r + 1], _C.p(ws), wsb, st))
+    total = torch.stack([view(ws, soff, 8, torch.float64) for ws in wss]).sum()
+    dz = torch.zeros_like(zc)
+    one = torch.ones(1, dtype=torch.float32, device='cuda')
+    for r, ws in enumerate(wss):
+        view(ws, soff, 8, torch.float64).fill_(total)
+        loss = torch.empty(1, dtype=torch.float32, device='cuda')
+        _C.check(lib.ppk_graphreg_sparse_finish(N, E, _C.p(loss), _C.p(ws), wsb, st))
+        part = torch.empty_like(zc)
+        _C.check(lib.ppk_graphreg_sparse_bwd(_C.p(zc), zc.stride(0), N, Z, E, _C.p(graph.rowptr), _C.p(graph.col), _C.p(graph.rev),
+                                             starts[r], starts[r + 1], _C.p(one), _C.p(part), part.stride(0), _C.p(ws), wsb, st))
+        dz += part
+        assert abs(float(loss) - float(whole.detach())) <= 1e-5 * abs(float(whole.detach())), (r, float(loss))
+    assert rel(dz.cpu().numpy(), z.grad.cpu().numpy()) <= 1e-4

@@ -94,8 +94,8 @@ def check_train_step(params, B, lo, hi, seed):
     loss = gpu.decode(z, dec, tgt)
     (loss + 0.3 * gpu.last_kl + 0.1 * z.pow(2).sum()).backward()
 
-    assert abs(float(loss) - float(loss_r)) <= 1e-5 * abs(float(loss_r))
-    assert abs(float(gpu.last_kl) - float(kl_r)) <= 1e-5 * abs(float(kl_r))
+    assert abs(float(loss.detach()) - float(loss_r.detach())) <= 1e-5 * abs(float(loss_r.detach()))
+    assert abs(float(gpu.last_kl.detach()) - float(kl_r.detach())) <= 1e-5 * abs(float(kl_r.detach()))
     assert rel(mu, mu_r) <= 1e-5 and rel(lv, lv_r) <= 1e-5 and rel(z, z_r) <= 1e-5
     refg = dict(ref.named_parameters())
     worst = 0.0
@@ -233,3 +233,26 @@ def test_full_size_batch_equals_weighted_halves():
             assert float(want.norm()) < 1e-9, name
             continue
         assert rel(want, g) <= 1e-4, (name, rel(want, g))
+
+
+@pytest.mark.parametrize('vocab,B', [(575, 40), (3000, 12)])
+def test_train_step_large_vocabulary(vocab, B):
+    """Vocabulary sizes of real SMILES / SELFIES languages (the pretrained PaccMann language has 575 tokens):
+    the cross-entropy rows, the output projection and the token table are far wider than in the other cases."""
+    params = dict(SMALL, vocab_size=vocab, embedding_size=24, rnn_cell_size=64)
+    check_train_step(params, B, 3, 14, 4000 + vocab)
+
+
+def test_train_step_long_sequences():
+    check_train_step(dict(SMALL, stack_depth=12), 3, 300, 420, 5001)
+
+
+def test_stack_beyond_the_lds_image_is_refused():
+    """The stack kernels hold one sequence's whole stack in LDS; a stack that does not fit is refused with an
+    error before anything is launched (no silent fallback)."""
+    from paccmann_polymer_amd import stack_gru_vae as M
+    params = dict(SMALL, stack_depth=400, stack_width=50)
+    enc = M.StackGRUEncoder(params).cuda()
+    seqs = make_batch(np.random.default_rng(0), 3, params['vocab_size'], 3, 6)
+    with pytest.raises((RuntimeError, ValueError)):
+        enc.encoder_train_step(pack_sequence(seqs, enforce_sorted=False))

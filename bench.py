@@ -137,11 +137,22 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    # PPK_BENCH_REHEARSAL=1: run the N > 1 code path on a box with fewer GPUs than ranks (ranks share the cards,
+    # gloo instead of RCCL, which refuses two ranks on one GPU).  A rehearsal of the control flow, never a
+    # measurement: the JSON line says so.
+    rehearsal = os.environ.get('PPK_BENCH_REHEARSAL') == '1'
+    if rehearsal:
+        import faulthandler
+        faulthandler.dump_traceback_later(90, exit=True)       # a rehearsal that hangs says where
+    dev_index = local_rank % torch.cuda.device_count() if rehearsal else local_rank
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
-    torch.cuda.set_device(local_rank)
-    device = torch.device('cuda', local_rank)
+        if rehearsal:
+            dist.init_process_group('gloo')
+        else:
+            dist.init_process_group('nccl', device_id=torch.device('cuda', dev_index))
+    torch.cuda.set_device(dev_index)
+    device = torch.device('cuda', dev_index)
 
     import paccmann_polymer_amd as P
     from paccmann_polymer_amd.paccmann_encoder import Encoder
@@ -186,7 +197,7 @@ def main():
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        t = torch.tensor([dt], dtype=torch.float64, device='cpu' if rehearsal else device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     ms_per_step = dt / args.steps * 1e3
@@ -227,6 +238,8 @@ def main():
                                     f'graph_gamma 1, Adam lr 1e-4, fp32', global_batch=B * world,
                            tokens_per_gpu=n_tokens, parallelism=f'dp{world}'),
                roofline=roofline, final_loss=float(loss))
+    if rehearsal:
+        out['rehearsal'] = 'ranks share GPUs over gloo: not a measurement'
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out['cpu_baseline'] = cpu_baseline()
     if rank == 0:

@@ -42,8 +42,16 @@ class GradSync:
         self.active = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
 
     def __call__(self):
-        if self.active:
-            dist.all_reduce(self.flat_grad, op=dist.ReduceOp.SUM, group=self.group)
+        if not self.active:
+            return
+        if self.flat_grad.is_cuda and dist.get_backend(self.group) == 'gloo':
+            # rehearsals with several ranks on one GPU: gloo's device-tensor all-reduce hangs on buffers of this
+            # size (both ranks inside all_reduce, 23 MB, PyTorch 2.10 ROCm), so the sum goes through host memory
+            host = self.flat_grad.cpu()
+            dist.all_reduce(host, op=dist.ReduceOp.SUM, group=self.group)
+            self.flat_grad.copy_(host)
+            return
+        dist.all_reduce(self.flat_grad, op=dist.ReduceOp.SUM, group=self.group)
 
 
 def dp_train_step(step_fn, optimizer, local_valid_tokens: int, total_valid_tokens: int, graph_gamma: float,

@@ -55,7 +55,9 @@ def train(epoch, model, train_loader, optimizer, scheduler, graph_gamma, growth_
     model.gru_vae.to(device)
     model.gru_vae.train()
     input_keep, start_index, end_index = 1., 2, 3
-    train_loss = 0
+    # the reference reads `loss.item()` every step (:105,:108): a host sync per bundle.  Here the three scalars stay
+    # on the device and are read once per epoch; the writer receives the same values, later.
+    history = []
     kl_scale = 0.0
     n_iter = len(train_loader)
     _iter = 0
@@ -79,14 +81,41 @@ def train(epoch, model, train_loader, optimizer, scheduler, graph_gamma, growth_
         loss = decoder_loss + graph_gamma * gr_loss
         loss.backward()
         optimizer.step()
-        if writer is not None:
-            step = _iter + epoch * n_iter
-            writer.add_scalar('recon_loss', decoder_loss, step)
-            writer.add_scalar('graph_loss', gr_loss, step)
-            writer.add_scalar('loss', loss.item(), step)
-        train_loss += loss.item()
+        history.append(torch.stack([decoder_loss.detach().reshape(()), gr_loss.detach().reshape(()), loss.detach().reshape(())]))
+    values = torch.stack(history).cpu().tolist() if history else []      # the epoch's only device-to-host read
+    if writer is not None:
+        for i, (dl, gl, l) in enumerate(values):
+            step = i + epoch * n_iter
+            writer.add_scalar('recon_loss', dl, step)
+            writer.add_scalar('graph_loss', gl, step)
+            writer.add_scalar('loss', l, step)
+    train_loss = sum(v[2] for v in values)
     if scheduler is not None:
         scheduler.step()
     logger.info(f"Learning rate {optimizer.param_groups[0]['lr']}\tkl_scale {kl_scale}")
     logger.info(f'{epoch}\t{train_loss / max(_iter, 1)}\t{time() - start_time}')
     return train_loss / max(_iter + 1, 1)
+
+
+def export_latents(model, pairs: Sequence[Sequence[torch.Tensor]], device=None, pairs_per_call: int = 2048):
+    """Downstream latent export (reference reactions_vae.py:229-260: for every item of the downstream dataset,
+    `z = model.encode(pack(seqs))` with batch size 2 and `z.view(1, -1)` -> one row of [len(seqs) * Z]).
+    The reference encodes one item per call; rows are independent, so `pairs_per_call` items go through the
+    sequence kernels together and the rows are cut afterwards — same values, one launch chain per chunk.
+    `pairs`: sequence of items, each a sequence of 1-D token tensors (all items the same count).
+    Returns a numpy array [n_items, count * Z]."""
+    device = get_device() if device is None else device
+    if len(pairs) == 0:
+        return np.zeros((0, 0), dtype=np.float32)
+    count = len(pairs[0])
+    if any(len(p) != count for p in pairs):
+        raise ValueError()
+    rows = []
+    for c0 in range(0, len(pairs), pairs_per_call):
+        chunk = pairs[c0:c0 + pairs_per_call]
+        seqs = [s for item in chunk for s in item]
+        model.update_batch_size(len(seqs))
+        encoder_seq, _, _ = packed_sequential_data_preparation(seqs, input_keep=1., start_index=2, end_index=3, device=device)
+        mu = model.encode(encoder_seq)
+        rows.append(mu.reshape(len(chunk), -1))
+    return torch.cat(rows).cpu().numpy()

@@ -107,3 +107,24 @@ def test_bundle_step_equals_sum_of_reference_steps():
     for p, g in zip(model.gru_vae.parameters(), ref_grads):
         if float(g.norm()) > 1e-10:
             assert float((p.grad - g).norm() / g.norm()) <= 1e-4
+
+
+def test_export_latents_equals_item_by_item_encoding():
+    """reactions_vae.py:229-260 encodes one downstream item (two SMILES) per call; the batched export cuts the
+    same rows out of one pass."""
+    from paccmann_polymer_amd.data_prep import packed_sequential_data_preparation
+    from paccmann_polymer_amd.paccmann_encoder import Encoder
+    from paccmann_polymer_amd.trainer import export_latents
+    rng = np.random.default_rng(8)
+    torch.manual_seed(8)
+    model = Encoder(PARAMS, None, None, batch_size=1, batch_mode='Packed')
+    model.gru_vae.eval()
+    pairs = [[torch.tensor(np.concatenate([[2], rng.integers(4, 30, size=int(rng.integers(2, 12))), [3]])) for _ in range(2)]
+             for _ in range(37)]
+    got = export_latents(model, pairs, pairs_per_call=16)
+    assert got.shape == (37, 2 * PARAMS['latent_dim'])
+    model.update_batch_size(2)
+    for i, seqs in enumerate(pairs):
+        e, _, _ = packed_sequential_data_preparation(seqs, input_keep=1., start_index=2, end_index=3, device='cuda')
+        want = model.encode(e).view(1, -1).squeeze().cpu().numpy()
+        assert np.allclose(got[i], want, rtol=1e-5, atol=1e-6), i

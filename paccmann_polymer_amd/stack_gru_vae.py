@@ -75,14 +75,19 @@ class _Linear(torch.autograd.Function):
         dw = torch.empty(N, K, dtype=torch.float32, device=dev)
         wsb = _lib.ppk_gemm_f32_workspace_bytes(N, K, M)
         ws = _ws(wsb, dev)
-        _C.check(_lib.ppk_gemm_f32(1, 0, N, K, M, 1.0, _C.p(dy), N, _C.p(x), K, 0.0,
-                                   _C.p(dw), K, None, _C.p(ws), wsb, _C.stream()))
-        db = None
-        if ctx.has_bias:
-            db = torch.empty(N, dtype=torch.float32, device=dev)
-            cb = _lib.ppk_colsum_workspace_bytes(M, N)
-            cws = _ws(cb, dev)
-            _C.check(_lib.ppk_colsum(_C.p(dy), N, M, N, 0.0, _C.p(db), _C.p(cws), cb, _C.stream()))
+        db = torch.empty(N, dtype=torch.float32, device=dev) if ctx.has_bias else None
+        rc = _C.PPK_ERR_UNSUP
+        if ctx.has_bias:                # dw = dy^T . x and db = column sums of dy from one pass over dy, when the shape allows
+            rc = _lib.ppk_gemm_tn_colsum_f32(N, K, M, _C.p(dy), N, _C.p(x), K, _C.p(dw), K, _C.p(db), _C.p(ws), wsb, _C.stream())
+            if rc != _C.PPK_ERR_UNSUP:
+                _C.check(rc)
+        if rc == _C.PPK_ERR_UNSUP:
+            _C.check(_lib.ppk_gemm_f32(1, 0, N, K, M, 1.0, _C.p(dy), N, _C.p(x), K, 0.0,
+                                       _C.p(dw), K, None, _C.p(ws), wsb, _C.stream()))
+            if ctx.has_bias:
+                cb = _lib.ppk_colsum_workspace_bytes(M, N)
+                cws = _ws(cb, dev)
+                _C.check(_lib.ppk_colsum(_C.p(dy), N, M, N, 0.0, _C.p(db), _C.p(cws), cb, _C.stream()))
         return dx, dw, db
 
 

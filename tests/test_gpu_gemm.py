@@ -60,6 +60,9 @@ def test_gemm_reproducible_splitk():
     c1 = ops.gemm(A, B, transA=True, ws=ws)
     c2 = ops.gemm(A, B, transA=True, ws=ws)
     assert torch.equal(c1, c2)
+    c3 = ops.gemm(A, B, transA=True, ws=False)                 # no workspace: no split-K, same product
+    assert torch.allclose(c3, c1, rtol=1e-4, atol=1e-2)
+    assert torch.equal(ops.gemm(A, B, transA=True), c1)        # ws=None allocates the workspace itself
     ref = A.double().T @ B.double()
     assert (c1.double() - ref).abs().max().item() <= 1e-5 * ref.abs().max().item()
 

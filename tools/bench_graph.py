@@ -98,6 +98,16 @@ def config3(small):
         t_conv = timeit(lambda: conv(x, g), iters=5)
     print(json.dumps(dict(kernel='GCNConv(256, 512) forward = K7 + fp32 MFMA GEMM', workload=wl, ms=round(t_conv * 1e3, 3),
                           gemm_tflops=round(2.0 * N * F * 512 / t_conv / 1e12, 1))), flush=True)
+    xg = x.clone().requires_grad_(True)
+    up = torch.randn(N, 512, device='cuda')
+
+    def fb():
+        xg.grad = None
+        conv.zero_grad(set_to_none=True)
+        conv(xg, g).backward(up)
+    t_fb = timeit(fb, iters=5)
+    print(json.dumps(dict(kernel='GCNConv(256, 512) forward + backward (2 x K7, 3 GEMMs, bias column sum)', workload=wl,
+                          ms=round(t_fb * 1e3, 3), gemm_tflops_if_all_gemm=round(6.0 * N * F * 512 / t_fb / 1e12, 1))), flush=True)
 
 
 def config4(small):
@@ -168,6 +178,7 @@ if __name__ == '__main__':
     ap = argparse.ArgumentParser()
     ap.add_argument('--small', action='store_true')
     args = ap.parse_args()
-    dense(args.small)
+    if not os.environ.get("PPK_BENCH_GRAPH_ONLY3"):
+        dense(args.small)
     config3(args.small)
     config4(args.small)

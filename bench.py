@@ -10,6 +10,7 @@ Prints ONE JSON line on rank 0.
 """
 import argparse
 import ctypes
+import faulthandler
 import json
 import os
 import sys
@@ -142,7 +143,6 @@ def main():
     # measurement: the JSON line says so.
     rehearsal = os.environ.get('PPK_BENCH_REHEARSAL') == '1'
     if rehearsal:
-        import faulthandler
         faulthandler.dump_traceback_later(90, exit=True)       # a rehearsal that hangs says where
     dev_index = local_rank % torch.cuda.device_count() if rehearsal else local_rank
     if world > 1:
@@ -239,6 +239,7 @@ def main():
                            tokens_per_gpu=n_tokens, parallelism=f'dp{world}'),
                roofline=roofline, final_loss=float(loss))
     if rehearsal:
+        faulthandler.cancel_dump_traceback_later()
         out['rehearsal'] = 'ranks share GPUs over gloo: not a measurement'
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out['cpu_baseline'] = cpu_baseline()

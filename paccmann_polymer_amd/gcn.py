@@ -91,6 +91,53 @@ def propagate(x, graph: CSRGraph):
     return _Propagate.apply(x, graph)
 
 
+class _MatmulBias(torch.autograd.Function):
+    """y = x @ W + b with W stored [in, out] as GCNConv keeps it.  Over millions of rows the NN kernel with 128 x 128
+    tiles is the fastest form of each product (tools/bench_gcn_gemm.py, 2.4 M x 256 x 512: forward 112 TFLOP/s against
+    106 through the transposed copy and the 64 x 64 NT tiles; input gradient 122 against 113), so the backward takes a
+    transposed copy of the 0.5 MB weight instead of re-reading 5 GB through the slower form; weight and bias gradient
+    come from one pass over dy."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        _C.require_gpu(x, weight, bias)
+        x, weight = x.contiguous(), weight.contiguous()
+        M, K = x.shape
+        N = weight.shape[1]
+        y = torch.empty(M, N, dtype=torch.float32, device=x.device)
+        _C.check(_lib.ppk_gemm_f32(0, 0, M, N, K, 1.0, _C.p(x), K, _C.p(weight), N, 0.0, _C.p(y), N, _C.p(bias), None, 0, _C.stream()))
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        dy = dy.contiguous()
+        M, K = x.shape
+        N = weight.shape[1]
+        dev = x.device
+        wt = weight.t().contiguous()                                   # [out, in]
+        dx = torch.empty_like(x)
+        _C.check(_lib.ppk_gemm_f32(0, 0, M, K, N, 1.0, _C.p(dy), N, _C.p(wt), K, 0.0, _C.p(dx), K, None, None, 0, _C.stream()))
+        dwt = torch.empty(N, K, dtype=torch.float32, device=dev)       # dy^T . x = dW^T
+        wsb = _lib.ppk_gemm_f32_workspace_bytes(N, K, M)
+        ws = _ws(wsb, dev)
+        db = torch.empty(N, dtype=torch.float32, device=dev) if ctx.has_bias else None
+        rc = _C.PPK_ERR_UNSUP
+        if ctx.has_bias:
+            rc = _lib.ppk_gemm_tn_colsum_f32(N, K, M, _C.p(dy), N, _C.p(x), K, _C.p(dwt), K, _C.p(db), _C.p(ws), wsb, _C.stream())
+            if rc != _C.PPK_ERR_UNSUP:
+                _C.check(rc)
+        if rc == _C.PPK_ERR_UNSUP:
+            _C.check(_lib.ppk_gemm_f32(1, 0, N, K, M, 1.0, _C.p(dy), N, _C.p(x), K, 0.0, _C.p(dwt), K, None, _C.p(ws), wsb, _C.stream()))
+            if ctx.has_bias:
+                cb = _lib.ppk_colsum_workspace_bytes(M, N)
+                cws = _ws(cb, dev)
+                _C.check(_lib.ppk_colsum(_C.p(dy), N, M, N, 0.0, _C.p(db), _C.p(cws), cb, _C.stream()))
+        return dx, dwt.t(), db
+
+
 class GCNConv(nn.Module):
     """torch_geometric.nn.GCNConv(in_channels, out_channels, cached=False) subset:
     unit edge weights, add_self_loops=True, normalize=True, bias=True."""
@@ -120,10 +167,9 @@ class GCNConv(nn.Module):
             graph = CSRGraph(edge_index.to(x.device), N)
             if self.cached:
                 self._cache = graph
-        wt = self.weight.t()          # linear() wants [out, in]; .t() view -> contiguous copy is 0.5 MB
         if self.in_channels <= self.out_channels:
-            return linear(propagate(x, graph), wt.contiguous(), self.bias)
-        out = propagate(linear(x, wt.contiguous(), None), graph)
+            return _MatmulBias.apply(propagate(x, graph), self.weight, self.bias)
+        out = propagate(_MatmulBias.apply(x, self.weight, None), graph)
         return out + self.bias if self.bias is not None else out
 
 

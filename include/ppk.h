@@ -99,6 +99,12 @@ size_t ppk_graphreg_sparse_workspace_bytes(int64_t N, int64_t E, int64_t zdim);
 int ppk_graphreg_sparse_dist(const float* z, int64_t ldz, int64_t N, int64_t zdim, const float* g, int64_t E,
                              const int64_t* rowptr, const int64_t* col, const int64_t* eid, int64_t a0, int64_t a1,
                              void* workspace, size_t ws_bytes, ppk_stream_t stream);
+/* dist for ALL anchors of a graph held by one GPU (a0 = 0, a1 = N), every undirected edge computed once:
+ * up [E] = CSR positions of the entries whose row is the smaller endpoint (ascending), up_row [E] = their rows.
+ * Leaves the workspace bit for bit as ppk_graphreg_sparse_dist(..., 0, N, ...) does, with half the gather traffic. */
+int ppk_graphreg_sparse_dist_once(const float* z, int64_t ldz, int64_t N, int64_t zdim, const float* g, int64_t E,
+                                  const int64_t* col, const int64_t* eid, const int64_t* up, const int64_t* up_row,
+                                  const int64_t* rev, void* workspace, size_t ws_bytes, ppk_stream_t stream);
 float*  ppk_graphreg_sparse_max_ptr(void* workspace, int64_t N, int64_t E);
 double* ppk_graphreg_sparse_sum_ptr(void* workspace, int64_t N, int64_t E);
 int ppk_graphreg_sparse_terms(int64_t N, int64_t E, const int64_t* rowptr, const int64_t* col, int64_t a0, int64_t a1,

@@ -76,6 +76,7 @@ SIGNATURES = {
     'ppk_dgi_loss_bwd': (c_int, [ptr, ptr, c_i64, ptr, ptr, ptr, ptr]),
     'ppk_graphreg_sparse_workspace_bytes': (c_sz, [c_i64, c_i64, c_i64]),
     'ppk_graphreg_sparse_dist': (c_int, [ptr, c_i64, c_i64, c_i64, ptr, c_i64, ptr, ptr, ptr, c_i64, c_i64, ptr, c_sz, ptr]),
+    'ppk_graphreg_sparse_dist_once': (c_int, [ptr, c_i64, c_i64, c_i64, ptr, c_i64, ptr, ptr, ptr, ptr, ptr, ptr, c_sz, ptr]),
     'ppk_graphreg_sparse_max_ptr': (ptr, [ptr, c_i64, c_i64]),
     'ppk_graphreg_sparse_sum_ptr': (ptr, [ptr, c_i64, c_i64]),
     'ppk_graphreg_sparse_terms': (c_int, [c_i64, c_i64, ptr, ptr, c_i64, c_i64, ptr, c_sz, ptr]),

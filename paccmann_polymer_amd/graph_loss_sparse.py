@@ -56,14 +56,28 @@ class SparseRelationGraph:
         pos_of[self.eid] = torch.arange(2 * E, dtype=torch.int64, device=dev)
         self.rev = pos_of[(self.eid + E) % (2 * E)].contiguous()
         self._anchor_starts = {}
+        self._up = None
 
-    def anchor_ranges(self, world: int, deg2_weight: float = 8.0):
+    def upper_entries(self):
+        """(up, up_row): CSR positions, ascending, of the entries whose anchor is the smaller endpoint, and their
+        rows — each undirected edge once (ppk_graphreg_sparse_dist_once)."""
+        if self._up is None:
+            deg = self.rowptr[1:] - self.rowptr[:-1]
+            row = torch.repeat_interleave(torch.arange(self.N, dtype=torch.int64, device=deg.device), deg)
+            up = torch.nonzero(row < self.col, as_tuple=False).reshape(-1).contiguous()
+            if up.numel() != self.E:
+                raise ValueError('edge_index must hold every undirected edge once and no self loops')
+            self._up = (up, row[up].contiguous())
+        return self._up
+
+    def anchor_ranges(self, world: int, deg2_weight: float = 4.0):
         """Work-balanced contiguous ANCHOR ranges for `world` ranks (independent of which rank owns a node's
         latent: z is all-gathered, any rank can evaluate any anchor).  Relation graphs are power-law: with
         equal node counts the rank that holds the hubs carries most of the sum(deg^2) comparisons (measured
         3.9 ms against ~1 ms on the others at 1 M nodes / 10 M edges).  Cost model per anchor:
         deg * 1000 (two latent rows of an entry from HBM) + deg2_weight * deg^2 (scalar comparisons per neighbour
-        pair; weights 1 / 4 / 16 / 64 scanned with tools/k5_balance_scan.py: slowest rank 4.9 / 4.6 / 4.4 / 5.5 ms)."""
+        pair; weights 0 / 1 / 2 / 4 / 8 / 16 scanned with tools/k5_balance_scan.py after the one-walk comparison kernel made the
+        deg^2 term cheaper: slowest rank 3.39 / 3.26 / 3.19 / 3.10 / 3.20 / 3.39 ms forward + backward)."""
         key = (world, float(deg2_weight))
         if key not in self._anchor_starts:
             deg = (self.rowptr[1:] - self.rowptr[:-1]).to(torch.float64)
@@ -89,8 +103,13 @@ class _SparseGraphLoss(torch.autograd.Function):
         wsb = _lib.ppk_graphreg_sparse_workspace_bytes(N, E, Z)
         ws = _ws(wsb, dev)
         st = _C.stream()
-        _C.check(_lib.ppk_graphreg_sparse_dist(_C.p(z), z.stride(0), N, Z, _C.p(graph.g), E, _C.p(graph.rowptr),
-                                               _C.p(graph.col), _C.p(graph.eid), a0, a1, _C.p(ws), wsb, st))
+        if a0 == 0 and a1 == N:         # the whole graph on this GPU: each undirected edge's distance once
+            up, up_row = graph.upper_entries()
+            _C.check(_lib.ppk_graphreg_sparse_dist_once(_C.p(z), z.stride(0), N, Z, _C.p(graph.g), E, _C.p(graph.col),
+                                                        _C.p(graph.eid), _C.p(up), _C.p(up_row), _C.p(graph.rev), _C.p(ws), wsb, st))
+        else:
+            _C.check(_lib.ppk_graphreg_sparse_dist(_C.p(z), z.stride(0), N, Z, _C.p(graph.g), E, _C.p(graph.rowptr),
+                                                   _C.p(graph.col), _C.p(graph.eid), a0, a1, _C.p(ws), wsb, st))
         base = ws.data_ptr()
         if group is not False:
             off = _lib.ppk_graphreg_sparse_max_ptr(_C.p(ws), N, E) - base

@@ -119,3 +119,38 @@ def test_full_size_anchor_ranges_sum_to_whole():
         dz += part
         assert abs(float(loss) - float(whole.detach())) <= 1e-5 * abs(float(whole.detach())), (r, float(loss))
     assert rel(dz.cpu().numpy(), z.grad.cpu().numpy()) <= 1e-4
+
+
+def test_dist_once_leaves_the_same_workspace_as_dist():
+    """ppk_graphreg_sparse_dist_once (each undirected edge once, mirrored through `rev`) against
+    ppk_graphreg_sparse_dist over all anchors: distances, attributes in CSR order and the max, bit for bit."""
+    import networkx as nx
+    from paccmann_polymer_amd import _C
+    from paccmann_polymer_amd.graph_loss_sparse import SparseRelationGraph
+    lib = _C.lib
+    rng = np.random.default_rng(4)
+    n, e, zd = 700, 5000, 96
+    gr = nx.gnm_random_graph(n, e, seed=4)
+    ei = np.asarray(list(gr.edges()), dtype=np.int64).T
+    flip = rng.random(ei.shape[1]) < 0.5
+    ei[:, flip] = ei[::-1][:, flip]
+    E = ei.shape[1]
+    graph = SparseRelationGraph(torch.tensor(ei).cuda(), torch.tensor(rng.integers(1, 5, size=E).astype(np.float32)).cuda(), n)
+    z = torch.randn(n, zd, device='cuda')
+    wsb = lib.ppk_graphreg_sparse_workspace_bytes(n, E, zd)
+    a, b = (torch.zeros(wsb, dtype=torch.uint8, device='cuda') for _ in range(2))
+    st = _C.stream()
+    _C.check(lib.ppk_graphreg_sparse_dist(_C.p(z), zd, n, zd, _C.p(graph.g), E, _C.p(graph.rowptr), _C.p(graph.col),
+                                          _C.p(graph.eid), 0, n, _C.p(a), wsb, st))
+    up, up_row = graph.upper_entries()
+    assert up.numel() == E and bool((up[1:] > up[:-1]).all())
+    _C.check(lib.ppk_graphreg_sparse_dist_once(_C.p(z), zd, n, zd, _C.p(graph.g), E, _C.p(graph.col), _C.p(graph.eid),
+                                               _C.p(up), _C.p(up_row), _C.p(graph.rev), _C.p(b), wsb, st))
+    assert torch.equal(a, b)
+    moff = lib.ppk_graphreg_sparse_max_ptr(_C.p(a), n, E) - a.data_ptr()
+    assert float(a[moff:moff + 4].view(torch.float32)) > 0
+    # a graph with a self loop is refused when the compacted list is built
+    bad = np.concatenate([ei, np.array([[3], [3]])], axis=1)
+    g2 = SparseRelationGraph(torch.tensor(bad).cuda(), torch.ones(E + 1).cuda(), n)
+    with pytest.raises(ValueError):
+        g2.upper_entries()

@@ -130,7 +130,8 @@ def config4(small):
     worst = {}
     for share, (a0, a1), frac in cases:
         wl = f'configs[3]: sparse graph-reg loss, N={N} nodes, E={E} undirected edges, Z={Z}, {share}'
-        by_f = 2 * E * frac * (2 * 4 * Z + 24) + 3 * 2 * E * frac * 4
+        # per UNDIRECTED edge two latent rows, the int64 pair and the attribute, plus d / g / coefficient scratch
+        by_f = E * frac * (2 * 4 * Z + 24) + 3 * E * frac * 4
         loss = _SparseGraphLoss.apply(z, graph, a0, a1, False)
         t_f = timeit(lambda: _SparseGraphLoss.apply(z.detach(), graph, a0, a1, False), iters=5)
 

@@ -1,5 +1,7 @@
 import sys, json
-sys.path.insert(0, '/root/repo'); sys.path.insert(0, '/root/repo/tools')
+import os
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tools'))
 import numpy as np, torch
 import bench_graph as bg
 from paccmann_polymer_amd.graph_loss_sparse import SparseRelationGraph, _SparseGraphLoss
@@ -12,7 +14,7 @@ graph = SparseRelationGraph(torch.tensor(und).cuda(), attr, N)
 z = torch.randn(N, Z, device='cuda', requires_grad=True)
 deg = (graph.rowptr[1:] - graph.rowptr[:-1])
 print('max deg', int(deg.max()), 'sum deg^2', float((deg.double() ** 2).sum()))
-for c in (1.0, 4.0, 16.0, 64.0):
+for c in (0.0, 0.5, 1.0, 2.0, 4.0, 8.0, 16.0):
     st = graph.anchor_ranges(8, c)
     ts = []
     for r in range(8):

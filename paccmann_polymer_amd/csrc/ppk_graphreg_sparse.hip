@@ -114,37 +114,60 @@ __global__ __launch_bounds__(256) void k_sp_dist_once(const float* __restrict__ 
     const long long k0 = ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * DIST_CHUNK;
     if (k0 >= E) return;
     const bool vec = !(zdim & 3) && !(ldz & 3) && !((uintptr_t)z & 15);
+    constexpr int STEPS = DIST_CHUNK / 4;
+    // the index chain (up -> col -> row address) of all steps first, clamped instead of branched, so that the row
+    // gathers of consecutive steps are independent loads
+    long long jj[STEPS];
+    const float* za[STEPS];
+    const float* zx[STEPS];
+#pragma unroll
+    for (int step = 0; step < STEPS; ++step) {
+        const long long k = k0 + step * 4 + sub;
+        const long long kk = k < E ? k : E - 1;
+        jj[step] = up[kk];
+        za[step] = z + up_row[kk] * ldz;
+    }
+#pragma unroll
+    for (int step = 0; step < STEPS; ++step) zx[step] = z + col[jj[step]] * ldz;
     float mx = 0.f;
 #pragma unroll
-    for (int step = 0; step < DIST_CHUNK / 4; ++step) {
-        const long long k = k0 + step * 4 + sub;
-        const bool on = k < E;
-        float acc = 0.f;
-        long long j = 0;
-        if (on) {
-            j = up[k];
-            const float* za = z + up_row[k] * ldz;
-            const float* zx = z + col[j] * ldz;
-            if (vec) {
-                for (int c0 = l16 * 4; c0 < zdim; c0 += 64) {
-                    const f32x4 p = *reinterpret_cast<const f32x4*>(za + c0), q = *reinterpret_cast<const f32x4*>(zx + c0);
+    for (int half = 0; half < STEPS; half += 2) {
+        float acc[2] = {0.f, 0.f};
+        if (vec) {
+            for (int c0 = l16 * 4; c0 < zdim; c0 += 64) {
+                f32x4 p[2], q[2];
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) { const float d = p[c] - q[c]; acc = fmaf(d, d, acc); }
+                for (int u = 0; u < 2; ++u) {
+                    p[u] = *reinterpret_cast<const f32x4*>(za[half + u] + c0);
+                    q[u] = *reinterpret_cast<const f32x4*>(zx[half + u] + c0);
                 }
-            } else {
-                for (int c0 = l16; c0 < zdim; c0 += 16) { const float d = za[c0] - zx[c0]; acc = fmaf(d, d, acc); }
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) { const float d = p[u][c] - q[u][c]; acc[u] = fmaf(d, d, acc[u]); }
+            }
+        } else {
+            for (int c0 = l16; c0 < zdim; c0 += 16)
+#pragma unroll
+                for (int u = 0; u < 2; ++u) { const float d = za[half + u][c0] - zx[half + u][c0]; acc[u] = fmaf(d, d, acc[u]); }
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            float a = acc[u];
+#pragma unroll
+            for (int o = 8; o > 0; o >>= 1) a += __shfl_xor(a, o, 64);
+            const float dist = sqrtf(a);
+            const long long k = k0 + (half + u) * 4 + sub;
+            if (k < E) {
+                if (l16 == 0) {
+                    const long long j = jj[half + u], r = rev[j];
+                    const float ge = g[eid[j] % E];
+                    dcsr[j] = dist; dcsr[r] = dist;
+                    gcsr[j] = ge;   gcsr[r] = ge;
+                }
+                mx = fmaxf(mx, dist);
             }
         }
-#pragma unroll
-        for (int o = 8; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
-        const float dist = sqrtf(acc);
-        if (on && l16 == 0) {
-            const long long r = rev[j];
-            const float ge = g[eid[j] % E];
-            dcsr[j] = dist; dcsr[r] = dist;
-            gcsr[j] = ge;   gcsr[r] = ge;
-        }
-        mx = fmaxf(mx, dist);
     }
     mx = ppk_wave_max(mx);
     if (lane == 0 && mx > 0.f && __float_as_uint(mx) > __hip_atomic_load(Mbits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))

@@ -198,18 +198,19 @@ __global__ __launch_bounds__(256) void k_sp_terms(const long long* __restrict__ 
         //              idy > idx  row raster, x = j, y = c           f(G_x - D_y ; D_x, D_y)   adds to S, t += f'
         //              between    row raster, y = j, x = c           f(G_y - D_x ; D_y, D_x)              t -= f'
         const bool xlow = idx < a;
-        for (int y = 0; y < deg; ++y) {
+#pragma unroll 4
+        for (int y = 0; y < deg; ++y) {                     // branch-free body: four partners' loads go out together
             const long long idy = col[j0 + y];
-            if (idy == idx) continue;                       // x itself
             const float dy = dcsr[j0 + y], gy = gcsr[j0 + y];
+            const bool other = idy != idx;                  // not x itself
             const bool lead = idy > idx;                    // x is the first argument
             const bool row_raster = !xlow && idy > a;
             const float cl = lead ? gx : gy;
             const float cr = row_raster ? (lead ? dy : dx) : (lead ? gy : gx);
             float dfa;
             const float f = reg_f(sgn_cmp(cl, cr), lead ? dx : dy, lead ? dy : dx, dfa);
-            Sx += lead ? f : 0.f;
-            t += lead ? dfa : -dfa;
+            Sx += lead ? f : 0.f;                           // x itself is never `lead`
+            t += other ? (lead ? dfa : -dfa) : 0.f;
         }
         T[e] = t;
         S = (double)Sx;

@@ -94,7 +94,8 @@ int ppk_graphreg_dense_bwd(const float* z, int64_t ldz, const int64_t* seg_ptr, 
  * SYMMETRISED edge list: entry ids e in [0, E) for u->v and E + e for v->u; rev [2E]
  * maps each entry to its reverse entry.  Anchors [a0, a1) let ranks own node ranges:
  * dist -> (MAX-all-reduce *max_ptr) -> terms -> (SUM-all-reduce *sum_ptr) -> finish;
- * bwd yields this rank's partial dz [N, zdim] (reduce-scatter across ranks). */
+ * bwd yields this rank's partial dz [N, zdim] (reduce-scatter across ranks).
+ * dist / dist_once with eid == NULL take g as [2E] attributes already in CSR order (permuted once per graph). */
 size_t ppk_graphreg_sparse_workspace_bytes(int64_t N, int64_t E, int64_t zdim);
 int ppk_graphreg_sparse_dist(const float* z, int64_t ldz, int64_t N, int64_t zdim, const float* g, int64_t E,
                              const int64_t* rowptr, const int64_t* col, const int64_t* eid, int64_t a0, int64_t a1,

@@ -90,7 +90,7 @@ __global__ __launch_bounds__(256) void k_sp_dist(const float* __restrict__ z, lo
         const float dist = sqrtf(acc);
         if (on && l16 == 0) {
             dcsr[j] = dist;
-            gcsr[j] = g[eid[j] % E];
+            if (eid) gcsr[j] = g[eid[j] % E];
         }
         mx = fmaxf(mx, dist);
     }
@@ -161,9 +161,11 @@ __global__ __launch_bounds__(256) void k_sp_dist_once(const float* __restrict__ 
             if (k < E) {
                 if (l16 == 0) {
                     const long long j = jj[half + u], r = rev[j];
-                    const float ge = g[eid[j] % E];
                     dcsr[j] = dist; dcsr[r] = dist;
-                    gcsr[j] = ge;   gcsr[r] = ge;
+                    if (eid) {                              // attributes given per edge: place them in CSR order
+                        const float ge = g[eid[j] % E];
+                        gcsr[j] = ge; gcsr[r] = ge;
+                    }
                 }
                 mx = fmaxf(mx, dist);
             }
@@ -451,6 +453,7 @@ size_t ppk_graphreg_sparse_workspace_bytes(int64_t N, int64_t E, int64_t zdim)
 }
 
 // Phase 1: distances of the edges incident to anchors [a0, a1), G into CSR order and the local max.
+// eid == NULL: `g` already holds the attributes in CSR order ([2E], the graph is static: permute once, not per call).
 // (rowptr, col, eid) is the CSR of the SYMMETRISED edge list (u->v for e in [0,E), v->u as E + e), 2E entries.
 // Mmax_bits [1] (in the workspace) can be MAX-all-reduced across ranks before phase 2: ppk_graphreg_sparse_max_ptr.
 int ppk_graphreg_sparse_dist(const float* z, int64_t ldz, int64_t N, int64_t zdim, const float* g, int64_t E,
@@ -459,9 +462,10 @@ int ppk_graphreg_sparse_dist(const float* z, int64_t ldz, int64_t N, int64_t zdi
 {
     int rc = sp_check(z, ldz, N, zdim, E, rowptr, col, a0, a1, workspace, ws_bytes);
     if (rc) return rc;
-    if (!g || !eid) PPK_FAIL(PPK_ERR_NULL, "graphreg_sparse_dist: null pointer");
+    if (!g) PPK_FAIL(PPK_ERR_NULL, "graphreg_sparse_dist: null pointer");
     SpWs w = sp_carve(workspace, N, 2 * E, 0);
     PPK_HIP(hipMemsetAsync(w.Mbits, 0, 256, stream));
+    if (!eid) PPK_HIP(hipMemcpyAsync(w.gcsr, g, sizeof(float) * (size_t)(2 * E), hipMemcpyDeviceToDevice, stream));   // g is [2E], CSR order
     {
         ppk::ProfScope prof(ppk::PK_GRAPHREG_SPARSE, (double)E * 2 * (2.0 * 4 * zdim + 24), stream);
         k_sp_dist<<<dim3(blocks_for((2 * E + DIST_CHUNK - 1) / DIST_CHUNK)), dim3(256), 0, stream>>>(z, ldz, (int)zdim, (const long long*)rowptr, (const long long*)col,
@@ -481,9 +485,10 @@ int ppk_graphreg_sparse_dist_once(const float* z, int64_t ldz, int64_t N, int64_
 {
     int rc = sp_check(z, ldz, N, zdim, E, col, col, 0, N, workspace, ws_bytes);
     if (rc) return rc;
-    if (!g || !eid || !up || !up_row || !rev) PPK_FAIL(PPK_ERR_NULL, "graphreg_sparse_dist_once: null pointer");
+    if (!g || !up || !up_row || !rev) PPK_FAIL(PPK_ERR_NULL, "graphreg_sparse_dist_once: null pointer");
     SpWs w = sp_carve(workspace, N, 2 * E, 0);
     PPK_HIP(hipMemsetAsync(w.Mbits, 0, 256, stream));
+    if (!eid) PPK_HIP(hipMemcpyAsync(w.gcsr, g, sizeof(float) * (size_t)(2 * E), hipMemcpyDeviceToDevice, stream));   // g is [2E], CSR order
     {
         ppk::ProfScope prof(ppk::PK_GRAPHREG_SPARSE, (double)E * (2.0 * 4 * zdim + 64), stream);
         k_sp_dist_once<<<dim3(blocks_for((E + DIST_CHUNK - 1) / DIST_CHUNK)), dim3(256), 0, stream>>>(

@@ -55,6 +55,7 @@ class SparseRelationGraph:
         pos_of = torch.empty(2 * E, dtype=torch.int64, device=dev)
         pos_of[self.eid] = torch.arange(2 * E, dtype=torch.int64, device=dev)
         self.rev = pos_of[(self.eid + E) % (2 * E)].contiguous()
+        self.g_csr = self.g[self.eid % E].contiguous()          # attributes in CSR order: the graph is static
         self._anchor_starts = {}
         self._up = None
 
@@ -105,11 +106,11 @@ class _SparseGraphLoss(torch.autograd.Function):
         st = _C.stream()
         if a0 == 0 and a1 == N:         # the whole graph on this GPU: each undirected edge's distance once
             up, up_row = graph.upper_entries()
-            _C.check(_lib.ppk_graphreg_sparse_dist_once(_C.p(z), z.stride(0), N, Z, _C.p(graph.g), E, _C.p(graph.col),
-                                                        _C.p(graph.eid), _C.p(up), _C.p(up_row), _C.p(graph.rev), _C.p(ws), wsb, st))
+            _C.check(_lib.ppk_graphreg_sparse_dist_once(_C.p(z), z.stride(0), N, Z, _C.p(graph.g_csr), E, _C.p(graph.col),
+                                                        None, _C.p(up), _C.p(up_row), _C.p(graph.rev), _C.p(ws), wsb, st))
         else:
-            _C.check(_lib.ppk_graphreg_sparse_dist(_C.p(z), z.stride(0), N, Z, _C.p(graph.g), E, _C.p(graph.rowptr),
-                                                   _C.p(graph.col), _C.p(graph.eid), a0, a1, _C.p(ws), wsb, st))
+            _C.check(_lib.ppk_graphreg_sparse_dist(_C.p(z), z.stride(0), N, Z, _C.p(graph.g_csr), E, _C.p(graph.rowptr),
+                                                   _C.p(graph.col), None, a0, a1, _C.p(ws), wsb, st))
         base = ws.data_ptr()
         if group is not False:
             off = _lib.ppk_graphreg_sparse_max_ptr(_C.p(ws), N, E) - base

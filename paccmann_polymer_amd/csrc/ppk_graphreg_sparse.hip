@@ -47,6 +47,17 @@ __device__ __forceinline__ long long row_of(const long long* __restrict__ rowptr
     return lo;
 }
 
+// the same for a lane whose entry e lies at most a few rows after the block's first entry e_first (consecutive CSR
+// entries): ONE block-uniform search (scalar loads) for e_first, then a short walk, instead of a divergent 20-step
+// binary search in every lane
+__device__ __forceinline__ long long row_of_near(const long long* __restrict__ rowptr, long long lo, long long hi,
+                                                 long long e_first, long long e)
+{
+    long long p = row_of(rowptr, lo, hi, e_first);
+    while (rowptr[p + 1] <= e) ++p;
+    return p;
+}
+
 constexpr int DIST_CHUNK = 16;     // CSR entries per wave in the distance pass (4 at a time, 16 lanes each)
 constexpr int DZ_CHUNK = 256;      // CSR entries per wave in the gradient pass
 
@@ -186,7 +197,7 @@ __global__ __launch_bounds__(256) void k_sp_terms(const long long* __restrict__ 
     const long long e = rowptr[a0] + (long long)blockIdx.x * 256 + threadIdx.x;
     double S = 0.0;
     if (e < rowptr[a1]) {
-        const long long a = row_of(rowptr, a0, a1, e);
+        const long long a = row_of_near(rowptr, a0, a1, rowptr[a0] + (long long)blockIdx.x * 256, e);
         const long long j0 = rowptr[a];
         const int deg = (int)(rowptr[a + 1] - j0);
         const long long idx = col[e];
@@ -267,7 +278,7 @@ __global__ __launch_bounds__(256) void k_sp_coef(long long N, const long long* _
     const float M = __uint_as_float(Mbits[0]);
     const float invM = 1.0f / M;
     const float gmax = (float)(-S[0] / ((double)M * (double)M));
-    const long long p = row_of(rowptr, 0, N, j);
+    const long long p = row_of_near(rowptr, 0, N, (long long)blockIdx.x * 256, j);
     const long long a = col[j];
     const bool own_p = p >= a0 && p < a1, own_a = a >= a0 && a < a1;
     float c = 0.f;

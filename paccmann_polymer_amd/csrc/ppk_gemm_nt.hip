@@ -216,7 +216,9 @@ __device__ __forceinline__ void gru_fwd_tokens_issue(const ppk::NtProblem& g, in
 #pragma unroll
     for (int i = 0; i < NP * 8; ++i) {
         int row = rbase + 8 * p0 + i; row = row < mlast ? row : mlast;
-        ts.v[i] = (int)tk[row];
+        int v = (int)tk[row];
+        v = v < 0 ? 0 : v; v = v < g.V ? v : g.V - 1;              // never index past the table (scalar ops)
+        ts.v[i] = v;
     }
 }
 template <int NP>
@@ -886,6 +888,7 @@ int gemm_ntF(const NtProblem* ps, int count, hipStream_t stream)
         } else if (p.epi == NT_GRU_FWD) {
             if (!p.gh || !p.hprev || !p.hnew || !p.hp_out || !p.gates_out) PPK_FAIL(PPK_ERR_NULL, "gemm_ntF: null GRU-forward operand");
             if (p.table && !p.tok) PPK_FAIL(PPK_ERR_NULL, "gemm_ntF: table without tokens");
+            if (p.table && p.V < 1) PPK_FAIL(PPK_ERR_SHAPE, "gemm_ntF: table without its row count");
         } else {
             PPK_FAIL(PPK_ERR_UNSUP, "gemm_ntF: epilogue %d not available on gate-layout tiles", p.epi);
         }

@@ -28,6 +28,7 @@ struct NtProblem {
     float* C; long long ldc; const float* bias; float beta;
     // NT_GRU_FWD (gate layout): gi = acc + bias (+ table[tok[row]]) ; gh [M,3H] holds W_hh h + b_hh
     const float* gh; const float* hprev; const int64_t* tok; const float* table;
+    int V;                       // rows of `table`: token ids are clamped to [0, V) in the kernel (the host validates them)
     float* hnew; float* hp_out; float* gates_out;          // [M,H], [M,H], [M,4H] = r, z, n, gh_n
     // NT_GRU_BWD: dh = acc + carry (+ ext) ; writes dgi, dgh [M,3H] and carry = dh * z
     float* carry; const float* ext; const float* gates_in; const float* hp_in; float* dgi; float* dgh;

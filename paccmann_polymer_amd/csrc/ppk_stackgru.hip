@@ -282,7 +282,7 @@ int ppk_stackgru_seq_fwd(int64_t T, const int64_t* batch_sizes_host, int64_t B, 
             int n = 0;
             ppk::NtProblem& c = ps[n++];
             c = ppk::NtProblem{};
-            if (l == 0) { c.A = XS + o * ks; c.lda = ks; c.K = (int)ks; c.B = wx0s; c.ldb = ks; c.tok = tokens + o; c.table = table; c.bias = nullptr; }
+            if (l == 0) { c.A = XS + o * ks; c.lda = ks; c.K = (int)ks; c.B = wx0s; c.ldb = ks; c.tok = tokens + o; c.table = table; c.V = (int)V; c.bias = nullptr; }
             else        { c.A = Hs + ((l - 1) * NT + o) * H; c.lda = H; c.K = (int)H; c.B = w_ih[l]; c.ldb = H; c.bias = b_ih[l]; }
             c.M = (int)Bt; c.N = (int)H3; c.a_rows = (int)Bt; c.H = (int)H; c.epi = ppk::NT_GRU_FWD;
             c.gh = gh[(size_t)l]; c.hprev = hprev(l);

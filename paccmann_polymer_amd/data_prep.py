@@ -8,11 +8,31 @@ Mirrors
 with bit-exact integer outputs (tests/test_data_prep.py pins them against
 torch.nn.utils.rnn.pack_sequence and networkx run on the same statements).
 """
+import weakref
 from typing import List, Sequence
 
 import numpy as np
 import torch
 from torch.nn.utils.rnn import PackedSequence, pack_sequence
+
+
+# Token-id ranges of device token streams built here, keyed by tensor identity.  The sequence kernels index a
+# [V, 3H] table with the token id; torch's Embedding raises (CPU) or asserts (GPU) on an id outside [0, V).  The ids
+# are host data while a batch is packed, so their range is recorded here for free and `StackGRU._run_sequence`
+# checks it against vocab_size without a device-to-host sync; streams of unknown provenance are checked once
+# (one sync) and remembered.
+_TOKEN_RANGES = {}
+
+
+def note_token_range(tensor, lo: int, hi: int):
+    key = id(tensor)
+    _TOKEN_RANGES[key] = (int(lo), int(hi))
+    weakref.finalize(tensor, _TOKEN_RANGES.pop, key, None)
+
+
+def known_token_range(tensor):
+    """(min, max) recorded for this very tensor object, or None."""
+    return _TOKEN_RANGES.get(id(tensor))
 
 
 def packed_sequential_data_preparation(
@@ -48,7 +68,10 @@ def packed_sequential_data_preparation(
     for entry in zip(*batch):
         # pack on the host (index arithmetic), ship the token stream once
         packed = pack_sequence([e.cpu() for e in entry], enforce_sorted=enforce_sorted)
-        out.append(PackedSequence(packed.data.to(device), packed.batch_sizes,
+        data_d = packed.data.to(device)
+        if packed.data.numel():
+            note_token_range(data_d, packed.data.min(), packed.data.max())
+        out.append(PackedSequence(data_d, packed.batch_sizes,
                                   None if packed.sorted_indices is None else packed.sorted_indices.to(device),
                                   None if packed.unsorted_indices is None else packed.unsorted_indices.to(device)))
     return out
@@ -76,8 +99,13 @@ def _packed_preparation_vectorised(input_batch, device):
     tgt = flat[torch.where(last, src, src + 1)]
     tgt = torch.where(last, torch.zeros_like(tgt), tgt)
     data_d, tgt_d = data.to(device), tgt.to(device)
+    dec_d = data_d.clone()
+    lo, hi = int(flat.min()), int(flat.max())
+    note_token_range(data_d, lo, hi)
+    note_token_range(dec_d, lo, hi)
+    note_token_range(tgt_d, min(lo, 0), hi)
     si, ui = sorted_idx.to(device), unsorted_idx.to(device)
-    return [PackedSequence(data_d, batch_sizes, si, ui), PackedSequence(data_d.clone(), batch_sizes, si, ui),
+    return [PackedSequence(data_d, batch_sizes, si, ui), PackedSequence(dec_d, batch_sizes, si, ui),
             PackedSequence(tgt_d, batch_sizes, si, ui)]
 
 
@@ -143,7 +171,7 @@ def hop_distance_matrices_device(edge_indices, num_nodes, order: str = 'networkx
     bundles of a step.  `edge_indices`: sequence of [2, E_k] integer arrays / tensors with LOCAL labels;
     `num_nodes`: sequence of n_k (each <= 64).  Returns (g_flat float64 device tensor holding the n_k x n_k
     matrices back to back — the layout `graph_loss_segmented` takes —, sizes, row_order int64 device tensor:
-    original label of every row).  Raises IndexError on labels outside [0, n_k)."""
+    original label of every row).  Raises IndexError on labels outside [0, n_k) (checked on the host: no sync)."""
     from . import _C
     if order not in ('networkx', 'index'):
         raise ValueError(order)
@@ -153,6 +181,11 @@ def hop_distance_matrices_device(edge_indices, num_nodes, order: str = 'networkx
     if len(sizes) != len(edge_indices) or not sizes:
         raise ValueError()
     eis = [np.asarray(e.cpu() if torch.is_tensor(e) else e, dtype=np.int64).reshape(2, -1) for e in edge_indices]
+    # labels are validated HERE, where the edge lists still are host data: reading the kernel's status word back would
+    # cost one device-to-host sync per bundle of trainer.train() (the kernel still skips bad edges and raises it)
+    for e, n in zip(eis, sizes):
+        if e.size and (int(e.min()) < 0 or int(e.max()) >= n):
+            raise IndexError('edge_index holds a node label outside [0, num_nodes)')
     edge_ptr = np.zeros(len(sizes) + 1, dtype=np.int64)
     edge_ptr[1:] = np.cumsum([e.shape[1] for e in eis])
     seg_ptr = np.zeros(len(sizes) + 1, dtype=np.int64)
@@ -172,8 +205,6 @@ def hop_distance_matrices_device(edge_indices, num_nodes, order: str = 'networkx
     _C.check(_C.lib.ppk_hop_distances(_C.p(esrc) if E else None, _C.p(edst) if E else None, _C.p(d_edge_ptr), _C.p(d_seg_ptr),
                                       _C.p(d_mat_ptr), K, max(sizes), 1 if order == 'networkx' else 0,
                                       _C.p(g), _C.p(row_order), _C.p(status), _C.stream()))
-    if int(status.item()) != 0:
-        raise IndexError('edge_index holds a node label outside [0, num_nodes)')
     return g, sizes, row_order
 
 

@@ -16,6 +16,7 @@ import math
 
 import torch
 import torch.nn as nn
+from torch.nn.utils.rnn import PackedSequence
 
 from . import _C
 from .stack_gru_vae import _Linear, _ws, linear
@@ -259,8 +260,34 @@ def default_summary(z, *args, **kwargs):
 
 
 def corruption(x, edge_index):
-    """utils.py:22-31 for tensor features: shuffle the rows."""
-    return x[torch.randperm(x.size(0), device=x.device)], edge_index
+    """utils.py:22-31.  Tensor features: rows shuffled with `torch.randperm(N)` drawn from the CPU generator, as
+    the reference draws it.  PackedSequence (the branch reactions_infomax.py:131 hits): the reference pads, permutes
+    the samples with the same `randperm` draw, and re-packs with `enforce_sorted=False`; the permuted batch holds the
+    same multiset of lengths, so the result is the same token stream gathered by index — computed here without the
+    [B, T] padded round trip, bit-identical in `data`, `batch_sizes`, `sorted_indices` and `unsorted_indices`
+    (tests/test_corruption.py runs the reference statements beside it)."""
+    if not isinstance(x, PackedSequence):
+        return x[torch.randperm(x.size(0)).to(x.device)], edge_index
+    bs = x.batch_sizes.to('cpu', torch.int64)
+    T, B = int(bs.numel()), int(bs[0])
+    dev = x.data.device
+    off = torch.zeros(T + 1, dtype=torch.int64)
+    off[1:] = torch.cumsum(bs, 0)
+    len_sorted = (bs.view(T, 1) > torch.arange(B, dtype=torch.int64).view(1, B)).sum(0)        # lengths in packed (sorted) order
+    unsorted = x.unsorted_indices.cpu() if x.unsorted_indices is not None else torch.arange(B, dtype=torch.int64)
+    lengths = len_sorted[unsorted]                                                             # ORIGINAL sample order (pad_packed_sequence)
+    idxs = torch.randperm(B)                                                                   # same draw as utils.py:27
+    new_len = lengths[idxs]
+    sorted_len, sorted_idx = torch.sort(new_len, descending=True)                              # pack_padded_sequence(enforce_sorted=False)
+    new_unsorted = torch.empty_like(sorted_idx)
+    new_unsorted[sorted_idx] = torch.arange(B, dtype=torch.int64)
+    # packed slot (t, i) of the corrupted batch holds step t of original sample idxs[sorted_idx[i]],
+    # which sits at packed slot (t, unsorted[that sample]) of the input
+    src_col = unsorted[idxs[sorted_idx]]
+    valid = torch.arange(T, dtype=torch.int64).view(T, 1) < sorted_len.view(1, B)
+    t_idx, i_idx = valid.nonzero(as_tuple=True)
+    src = (off[t_idx] + src_col[i_idx]).to(dev)
+    return PackedSequence(x.data[src], bs, sorted_idx.to(dev), new_unsorted.to(dev)), edge_index
 
 
 class DeepGraphInfomax(nn.Module):

@@ -30,6 +30,7 @@ import torch.nn as nn
 from torch.nn.utils.rnn import PackedSequence
 
 from . import _C
+from .data_prep import known_token_range, note_token_range
 
 _lib = _C.lib
 
@@ -441,13 +442,18 @@ class StackGRU(nn.Module):
             raise NotImplementedError('dropout > 0 in training mode is not implemented in the HIP path')
         dev = self.embedding.weight.device
         tokens = packed.data
+        # ids index a [V, 3H] table inside the kernels: validate like nn.Embedding does (IndexError), on the host copy
+        # of the range when data_prep recorded one, otherwise once per token tensor (one sync, then remembered)
+        rng = known_token_range(tokens)
+        if rng is None and tokens.numel():
+            lo, hi = torch.aminmax(tokens)
+            rng = (int(lo), int(hi))
+            note_token_range(tokens, *rng)
+        if rng is not None and (rng[0] < 0 or rng[1] >= self.vocab_size):
+            raise IndexError('token index out of range')
         if tokens.dim() != 1:
             tokens = tokens.reshape(-1)
-        if not tokens.is_cuda:
-            if tokens.numel() and (int(tokens.max()) >= self.vocab_size or int(tokens.min()) < 0):
-                raise IndexError('token index out of range')
-            tokens = tokens.to(dev)
-        tokens = tokens.to(torch.int64).contiguous()
+        tokens = tokens.to(device=dev, dtype=torch.int64).contiguous()
         bs = packed.batch_sizes.to('cpu', torch.int64)
         return _StackGRUSeq.apply(tokens, bs, self._dims(), h0, self.embedding.weight,
                                   self.stack_controls_layer.weight, self.stack_controls_layer.bias,

@@ -205,6 +205,13 @@ int ppk_scatter_rows(const float* src, int64_t ld_src, const int64_t* idx, int64
 size_t ppk_colsum_workspace_bytes(int64_t rows, int64_t cols);
 int ppk_colsum(const float* A, int64_t lda, int64_t rows, int64_t cols, float beta, float* out,
                void* workspace, size_t ws_bytes, ppk_stream_t stream);
+/* ppk_colsum WITHOUT a workspace and without any allocation.  No counterpart in the reference: it exists for callers
+ * that cannot allocate device memory — code under HIP graph capture, tight serving loops, harnesses that forbid
+ * hipMalloc.  The partial sums live in a 1 MiB file-scope device array of the library (one copy per GPU, held until the
+ * process ends, reached through hipGetSymbolAddress on the current device at the first call on that device).
+ * Limit: ceil(rows / 512) * cols <= 262144, otherwise PPK_ERR_UNSUP with nothing launched.  Bit-identical to ppk_colsum.
+ * All calls on one GPU share that GPU's array: calls that overlap on one GPU (streams, threads) race. */
+int ppk_colsum_noalloc(const float* A, int64_t lda, int64_t rows, int64_t cols, float beta, float* out, ppk_stream_t stream);
 size_t ppk_embedding_bwd_workspace_bytes(int64_t NT, int64_t V, int64_t E);
 int ppk_embedding_bwd(const float* dX, int64_t ldx, const int64_t* tokens, int64_t NT, int64_t V, int64_t E,
                       int64_t padding_idx, float* dEmb, void* workspace, size_t ws_bytes, ppk_stream_t stream);

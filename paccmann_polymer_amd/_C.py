@@ -57,6 +57,7 @@ SIGNATURES = {
     'ppk_scatter_rows': (c_int, [ptr, c_i64, ptr, c_i64, c_i64, ptr, c_i64, c_i64, ptr]),
     'ppk_colsum_workspace_bytes': (c_sz, [c_i64, c_i64]),
     'ppk_colsum': (c_int, [ptr, c_i64, c_i64, c_i64, c_f32, ptr, ptr, c_sz, ptr]),
+    'ppk_colsum_noalloc': (c_int, [ptr, c_i64, c_i64, c_i64, c_f32, ptr, ptr]),
     'ppk_embedding_bwd_workspace_bytes': (c_sz, [c_i64, c_i64, c_i64]),
     'ppk_embedding_bwd': (c_int, [ptr, c_i64, ptr, c_i64, c_i64, c_i64, c_i64, ptr, ptr, c_sz, ptr]),
     'ppk_ce_workspace_bytes': (c_sz, [c_i64]),

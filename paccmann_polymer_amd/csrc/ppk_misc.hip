@@ -2,8 +2,18 @@
 // column sums, embedding gradient, logits cross-entropy (K2), reparameterise +
 // KL (K3), flat Adam.  Every reduction has a fixed order (no float atomics).
 #include "ppk_common.h"
+#include <mutex>
 
 namespace {
+
+// Scratch of ppk_colsum_noalloc: the per-chunk partial column sums that ppk_colsum keeps in its caller-provided
+// workspace.  Every GPU the library runs on holds its own copy of this array until the process ends.  In host code
+// the NAME is only a handle for hipGetSymbolAddress — never a device address: kernels get the per-device pointer.
+constexpr size_t NOALLOC_FLOATS = (size_t)1 << 18;             // 1 MiB
+constexpr int NOALLOC_MAX_DEVICES = 64;
+static __device__ __align__(256) float scratch[NOALLOC_FLOATS];
+float* g_scratch_ptr[NOALLOC_MAX_DEVICES];
+std::mutex g_scratch_mutex;
 
 inline unsigned grid_for(long long work, unsigned cap = 4096)
 {
@@ -343,6 +353,42 @@ int ppk_colsum(const float* A, int64_t lda, int64_t rows, int64_t cols, float be
     k_colsum_part<<<grid, dim3(256), 0, stream>>>(A, lda, rows, (int)cols, (float*)workspace);
     PPK_CHECK_LAUNCH("k_colsum_part");
     k_colsum_final<<<dim3((unsigned)((cols + 31) / 32)), dim3(256), 0, stream>>>((const float*)workspace, nparts, (int)cols, beta, out);
+    PPK_CHECK_LAUNCH("k_colsum_final");
+    return PPK_OK;
+}
+
+// ppk_colsum for callers that cannot allocate (HIP graph capture, serving loops): the partials live in the
+// library's own file-scope device array, reached through the address hipGetSymbolAddress returns for the CURRENT
+// device (looked up once per device).  No hipMalloc / hipFree / allocating call on this path.  All calls on one GPU
+// share that GPU's array: calls that overlap on one GPU (two streams, two threads) race.  Nothing has to start at
+// zero — pass 1 overwrites every partial pass 2 reads — so a call does not depend on what the last one left.
+int ppk_colsum_noalloc(const float* A, int64_t lda, int64_t rows, int64_t cols, float beta, float* out, hipStream_t stream)
+{
+    if (cols == 0) return PPK_OK;
+    if (!A || !out) PPK_FAIL(PPK_ERR_NULL, "colsum_noalloc: null pointer");
+    if (rows < 1 || cols < 1 || lda < cols) PPK_FAIL(PPK_ERR_SHAPE, "colsum_noalloc: bad sizes");
+    const int64_t nparts = (rows + CS_CHUNK - 1) / CS_CHUNK;
+    if (nparts > 65535 || (uint64_t)nparts * (uint64_t)cols > NOALLOC_FLOATS)
+        PPK_FAIL(PPK_ERR_UNSUP, "colsum_noalloc: ceil(rows / %d) * cols = %lld exceeds the built-in scratch of %zu floats (use ppk_colsum with a workspace)",
+                 CS_CHUNK, (long long)(nparts * cols), NOALLOC_FLOATS);
+    int dev = -1;
+    PPK_HIP(hipGetDevice(&dev));
+    if (dev < 0 || dev >= NOALLOC_MAX_DEVICES) PPK_FAIL(PPK_ERR_UNSUP, "colsum_noalloc: device index %d not supported", dev);
+    float* part = nullptr;
+    {
+        std::lock_guard<std::mutex> lock(g_scratch_mutex);
+        if (!g_scratch_ptr[dev]) {
+            void* sym = nullptr;
+            PPK_HIP(hipGetSymbolAddress(&sym, HIP_SYMBOL(scratch)));        // this device's copy of the array
+            if (!sym) PPK_FAIL(PPK_ERR_HIP, "colsum_noalloc: hipGetSymbolAddress returned null");
+            g_scratch_ptr[dev] = (float*)sym;
+        }
+        part = g_scratch_ptr[dev];
+    }
+    dim3 grid((unsigned)((cols + 255) / 256), (unsigned)nparts);
+    k_colsum_part<<<grid, dim3(256), 0, stream>>>(A, lda, rows, (int)cols, part);
+    PPK_CHECK_LAUNCH("k_colsum_part");
+    k_colsum_final<<<dim3((unsigned)((cols + 31) / 32)), dim3(256), 0, stream>>>(part, (int)nparts, (int)cols, beta, out);
     PPK_CHECK_LAUNCH("k_colsum_final");
     return PPK_OK;
 }

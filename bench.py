@@ -229,7 +229,7 @@ def main():
              for k in range(nk) if launches[k]]
     kinds.sort(key=lambda d: -d['ms'])
     top = kinds[0]
-    is_gemm = top['kernel'].startswith(('k_gemm', 'k_nt', 'k_tn'))        # fp32-MFMA GEMM families: work = FLOPs
+    is_gemm = top['kernel'].startswith(('k_gemm', 'k_nt', 'k_tn', 'k_seq'))        # fp32-MFMA GEMM families: work = FLOPs
     achieved = top['work'] / (top['ms'] * 1e-3) / (1e12 if is_gemm else 1e9)
     peak = PEAK_FP32_MFMA_TFLOPS if is_gemm else PEAK_HBM_GBS
     roofline = dict(bound='mfma' if is_gemm else 'hbm', achieved=round(achieved, 2), peak=peak,

@@ -150,6 +150,12 @@ int ppk_gemm_tn_colsum_f32(int64_t M, int64_t N, int64_t K, const float* A, int6
  * limit < -1 only queries; returns the value in force. */
 int64_t ppk_nt_small_grid_limit(int64_t limit);
 
+/* Tuning / test hook of K1: the sequence entry points run the whole time loop as ONE persistent launch (row-block
+ * groups synchronised among their own workgroups only) whenever the shape allows; mode 0 switches that off
+ * (one launch per layer-step, the round-1 schedule), -1 / 1 switch it back on, any other value only queries.
+ * Process-global like ppk_nt_small_grid_limit.  Returns the value in force. */
+int ppk_seq_persist_mode(int mode);
+
 /* ---- K1: stack-augmented GRU sequence (packed, length-sorted batch) -------
  * Replaces the per-timestep loop of paccmann_chemistry StackGRU / nn.GRU that
  * the reference drives from paccmann_polymer/models/paccmann_encoder.py:166

@@ -48,7 +48,7 @@ const char* const kKindNames[ppk::PK_COUNT] = {
     "k_gemm<128,128,XX>", "k_gemm<128,128,XK>", "k_gemm<128,128,KX>", "k_gemm<128,128,KK>",
     "k_stack_fwd", "k_stack_bwd",
     "k_terms", "k_dz", "k_spmm", "k_graphreg_sparse",
-    "k_nt64", "k_ntF", "k_nt32", "k_ntFs", "k_tn128",
+    "k_nt64", "k_ntF", "k_nt32", "k_ntFs", "k_tn128", "k_seq_fwd", "k_seq_bwd",
 };
 }  // namespace
 

@@ -38,6 +38,19 @@ int gemm_nt64(const NtProblem* ps, int count, hipStream_t stream);   // 64 x 64 
 int gemm_ntF(const NtProblem* ps, int count, hipStream_t stream);    // 128 x (3 x 32) gate-layout tiles: NT_STORE, NT_GRU_FWD
 
 
+// ---- persistent StackGRU sequence kernels (ppk_seq_persist.hip): the whole time loop in one launch,
+//      row-block groups synchronised only among their own workgroups ----
+constexpr int SEQP_MAXT = 512, SEQP_MAXL = 8;
+int seq_persist_mode(int mode);      // -1 auto (default), 0 never, 1 whenever supported; other values only query
+bool seq_fwd_persist_ok(int64_t T, int64_t B, int64_t NT, int64_t H, int64_t L, int64_t W, int64_t D, int64_t ks, int64_t ldcs);
+size_t seq_fwd_persist_ws_bytes(int64_t B, int64_t H, int64_t L, int64_t W);
+int seq_fwd_persist(int64_t T, const int64_t* bs, int64_t B, int64_t NT, int64_t V, int64_t H, int64_t L, int64_t W, int64_t D,
+                    const int64_t* tokens, const float* table, const float* wx0s, int64_t ks,
+                    const float* const* w_ih, const float* const* w_hh, const float* const* b_ih, const float* const* b_hh,
+                    const float* wcs, const float* bcs, const float* h0, const float* S0,
+                    float* XS, float* Hs, float* HP, float* gates, float* S, float* CS, int64_t ldcs,
+                    void* ws, size_t ws_bytes, hipStream_t stream);
+
 // ---- opt-in per-kernel timing (HIP events on the launch stream) -------------
 // Off by default; bench.py switches it on for ONE extra step after the timed
 // region to price each kernel family against its roofline.
@@ -46,7 +59,7 @@ enum ProfKind {
     PK_GEMM_L_XX, PK_GEMM_L_XK, PK_GEMM_L_KX, PK_GEMM_L_KK,          // 128x128 tiles
     PK_STACK_FWD, PK_STACK_BWD,
     PK_GRAPHREG_TERMS, PK_GRAPHREG_DZ, PK_SPMM, PK_GRAPHREG_SPARSE,
-    PK_GEMM_NT64, PK_GEMM_NTF, PK_GEMM_NT32, PK_GEMM_NTFS, PK_GEMM_TN128,
+    PK_GEMM_NT64, PK_GEMM_NTF, PK_GEMM_NT32, PK_GEMM_NTFS, PK_GEMM_TN128, PK_SEQ_FWD, PK_SEQ_BWD,
     PK_COUNT
 };
 struct ProfScope {

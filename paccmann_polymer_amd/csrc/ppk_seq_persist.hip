@@ -1,0 +1,658 @@
+// K1 forward as ONE persistent launch: the whole packed StackGRU time loop
+// (paccmann_chemistry StackGRU reached from paccmann_polymer/models/paccmann_encoder.py:166,168;
+// semantics SURVEY.md Appendix B) without a kernel boundary per layer-step.
+//
+// The recurrence is sequential in TIME but independent across batch ROWS.  Rows are cut into
+// "m-tiles" of 32 consecutive rows of the length-sorted batch; a GROUP owns two m-tiles — one from
+// the long end and one from the short end of the batch (m-tiles g and 2G-1-g: every group carries
+// the same number of row-steps) — and is served by H/32 workgroups, one per 32 hidden units
+// ("n-tile": r, z, n of the same units, so the GRU cell runs in the epilogue).  A workgroup only
+// ever waits for the other workgroups of ITS group (a counter per group and phase); groups drift
+// freely, two workgroups of different groups share a CU, and one's epilogue / stack update / wait
+// overlaps the other's MFMA loop.  There is no grid-wide barrier anywhere.
+//
+// Per step and layer l a workgroup computes, for its units u and the group's active rows,
+//   acc_r, acc_z += W_hh[l] h_l(t-1)            "part A": operands complete one phase earlier,
+//   acc_nh       += W_hn[l] h_l(t-1)              so this runs while the group's slower members finish
+//   acc_r, acc_z, acc_ni += W_ih[l] x_l(t)      "part B": x_0 = stack top (K = ks), x_l = h_{l-1}(t)
+// with fp32 MFMA 32x32x2.  K tiles of 32 are staged for the whole workgroup by LDS-DMA
+// (global_load_lds, source-side XOR swizzle, 3 buffers, one s_barrier per K tile); inside a K tile the
+// four waves split K (wave w takes the 8-wide chunk w) and each wave accumulates ALL active m-tiles x
+// gates: when the short m-tile of a group has ended, every wave still has work (half of it) instead
+// of two waves idling.  The four partial tiles are summed in wave order in the epilogue (fixed
+// order: bitwise reproducible).  After the top layer, each workgroup updates the stack rows it owns
+// (stack heads on the VALU from a transposed [H, 3+W] weight copy, push/pop/no-op blend) and
+// publishes the new stack tops.
+//
+// Cross-workgroup hand-offs (hidden tiles, stack tops) follow MI355X_MICROARCH.md's valid forms:
+// producer = write-through (sc1) 16-byte stores, every wave drains vmcnt, workgroup barrier, ONE
+// agent-scope counter add; consumer = ONE lane polls (relaxed, agent), agent acquire (buffer_inv sc1),
+// vmcnt(0), workgroup barrier, then plain loads / LDS-DMA.  Every hand-off line is written once
+// before any reader touches it and by exactly one workgroup (128-byte row segments).  Polls are
+// bounded: on a timeout the kernel raises a status word and every workgroup leaves.
+#include "ppk_common.h"
+#include "ppk_kernels.h"
+#include <stdlib.h>
+#include <algorithm>
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int BK = 32;
+constexpr int MAXT = ppk::SEQP_MAXT, MAXL = ppk::SEQP_MAXL;
+constexpr int STG_BUF = 5 * 1024;              // floats per staging buffer: A slot 0, A slot 1, B r, B z, B n (32 x 32 each)
+constexpr int NBUF = 3;
+constexpr int EPI_LD = 36;                     // floats per transposed row (16-B aligned, bank-friendly)
+constexpr int EPI_TILE = 32 * EPI_LD;
+constexpr int REGION = 4 * 4 * EPI_TILE;       // floats: 4 waves x 4 accumulators, transposed (also staging / stack scratch)
+constexpr int SPIN_LIMIT = 1 << 22;            // polls of ~0.3 us: > 1 s
+static_assert(NBUF * STG_BUF <= REGION, "staging fits the shared region");
+
+#define PPK_LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
+
+struct SeqArgs {
+    int T, B, H, L, W, D, V, ks, ldcs, ntiles, G, MT, g0, g1, tpx, rb;
+    long long NT;
+    const int64_t* tokens;
+    const float* table; const float* wx0s;
+    const float* w_ih[MAXL]; const float* w_hh[MAXL]; const float* b_ih[MAXL]; const float* b_hh[MAXL];
+    const float* wcs_t; const float* bcs; const float* h0; const float* S0;
+    float* XS; float* Hs; float* HP; float* gates; float* S; float* CS;
+    float* hpart;
+    int* ctr; int* status;
+    long long* dbg;
+    int bs[MAXT];
+};
+
+template <int N> __device__ __forceinline__ void wait_vmcnt()
+{
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+__device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+__device__ __forceinline__ void st4(float* p, const f32x4& v) { *reinterpret_cast<f32x4*>(p) = v; }
+// write-through 16-byte store (sc1): the bytes are at the coherence point once the wave's vmcnt drains
+__device__ __forceinline__ void st4_sc1(float* p, const f32x4& v)
+{
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+}
+
+// ---- group-local synchronisation ----------------------------------------------------------
+// every wave has drained its stores -> barrier -> one counter add
+__device__ __forceinline__ void group_signal(int* ctr)
+{
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_fetch_add(ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// one lane polls, acquires, then the workgroup barrier; false = timeout / another workgroup gave up
+__device__ __forceinline__ bool group_wait(int* ctr, int target, int* status, volatile int* flag)
+{
+    if (threadIdx.x == 0) {
+        int ok = 0;
+        for (int it = 0; it < SPIN_LIMIT; ++it) {
+            if (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target) { ok = 1; break; }
+            if ((it & 255) == 255 && __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
+            __builtin_amdgcn_s_sleep(8);
+        }
+        if (!ok) __hip_atomic_store(status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        *flag = ok;
+    }
+    __syncthreads();
+    const bool ok = *flag != 0;
+    __syncthreads();
+    return ok;
+}
+
+// ---- K loop ---------------------------------------------------------------------------------
+// acc[s][q] += A_s[32 x 32 nk] . B_q[32 x 32 nk]^T for the NA active m-tiles s and the gates q = r, z, n (n goes to
+// accumulator NSEL: 2 = input side, 3 = hidden side); the wave takes chunk `wave` of every K tile.
+// src[0..1]: this lane's source of its LDS-DMA piece of A slot 0 / 1, src[2..4]: of B gate r / z / n.
+template <int NA, int NSEL>
+__device__ __forceinline__ void kloop(float* lds, const float* s0, const float* s1, const float* s2, const float* s3, const float* s4,
+                                      int nk, f32x16 (&acc)[2][4], int wave, int lane)
+{
+    constexpr int PPW = 3 + NA;
+    const int li = lane & 31, h = lane >> 5;
+    const int xo = li * BK + 4 * ((2 * wave + h) ^ ((li >> 1) & 7));
+    auto stage = [&](int buf) {
+        float* base = lds + buf * STG_BUF + wave * 256;
+        __builtin_amdgcn_global_load_lds(s0, PPK_LDS_PTR(base), 16, 0, 0); s0 += BK;
+        if constexpr (NA == 2) { __builtin_amdgcn_global_load_lds(s1, PPK_LDS_PTR(base + 1024), 16, 0, 0); s1 += BK; }
+        __builtin_amdgcn_global_load_lds(s2, PPK_LDS_PTR(base + 2048), 16, 0, 0); s2 += BK;
+        __builtin_amdgcn_global_load_lds(s3, PPK_LDS_PTR(base + 3072), 16, 0, 0); s3 += BK;
+        __builtin_amdgcn_global_load_lds(s4, PPK_LDS_PTR(base + 4096), 16, 0, 0); s4 += BK;
+    };
+    __syncthreads();                                  // the shared region is free (previous epilogue / stack phase done)
+    if (nk > 0) stage(0);
+    if (nk > 1) stage(1);
+    int cur = 0, nxt = 2;
+    for (int it = 0; it < nk; ++it) {
+        if (it + 1 < nk) wait_vmcnt<PPW>(); else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (it + 2 < nk) stage(nxt);
+        nxt = nxt == NBUF - 1 ? 0 : nxt + 1;
+        const float* base = lds + cur * STG_BUF + xo;
+        f32x4 a[NA], b[3];
+#pragma unroll
+        for (int s = 0; s < NA; ++s) a[s] = *(const f32x4*)(base + s * 1024);
+#pragma unroll
+        for (int q = 0; q < 3; ++q) b[q] = *(const f32x4*)(base + (2 + q) * 1024);
+#pragma unroll
+        for (int st = 0; st < 4; ++st)
+#pragma unroll
+            for (int s = 0; s < NA; ++s) {
+                acc[s][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s][st], b[0][st], acc[s][0], 0, 0, 0);
+                acc[s][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s][st], b[1][st], acc[s][1], 0, 0, 0);
+                acc[s][NSEL] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s][st], b[2][st], acc[s][NSEL], 0, 0, 0);
+            }
+        cur = cur == NBUF - 1 ? 0 : cur + 1;
+    }
+}
+
+__device__ __forceinline__ void tile_to_lds(float* t, const f32x16& acc, int li, int h)
+{
+#pragma unroll
+    for (int r = 0; r < 16; ++r) t[((r & 3) + 8 * (r >> 2) + 4 * h) * EPI_LD + li] = acc[r];
+}
+
+// this lane's LDS-DMA source inside a [rows x K] row-major operand: row `row` (already clamped), swizzled 16-B chunk
+__device__ __forceinline__ const float* dma_src(const float* base, long long row, long long ld, int i, int lane)
+{
+    return base + row * ld + 4 * ((lane & 7) ^ ((i >> 1) & 7));
+}
+
+// ---- stack heads, distributed: every n-tile workgroup multiplies ITS 32 hidden units of the top layer's new hidden
+// tile with its slice of the transposed head weights, P[row][o] = sum_c h[row][c] wcs_t[32 j + c][o], and hands the
+// partial to the owner of the row, which adds the ntiles partials in tile order (fixed order).  The K = H contraction
+// of the heads is thereby split over the workgroups that already hold the operands; nobody streams all of W_c / W_s.
+//   hpart [(g ntiles + j) 64 + 32 slot + row][ldcs]      (rewritten every step: write-through stores, sc1 loads behind
+//                                                          the acquire on the reading side)
+// (noinline, called while no accumulator is live; small by-value context: the 2.5 KB argument block stays in the kernarg segment)
+struct HeadsCtx { const float* wslice; float* dst; int ldcs, n0, n1; };
+__device__ __noinline__ void heads_partial(HeadsCtx c, float* lds, f32x4 ho0, f32x4 ho1)
+{
+    const int tid = threadIdx.x, er = tid >> 3, c4 = (tid & 7) * 4, og = tid & 7, ldcs = c.ldcs;
+    float* hs = lds;                                  // [2][32][EPI_LD]
+    float* wl = lds + 2 * EPI_TILE;                   // [32][ldcs]
+    __syncthreads();                                  // the partial sums of the last m-tile have been read
+    st4(hs + er * EPI_LD + c4, er < c.n0 ? ho0 : f32x4{0.f, 0.f, 0.f, 0.f});
+    st4(hs + EPI_TILE + er * EPI_LD + c4, er < c.n1 ? ho1 : f32x4{0.f, 0.f, 0.f, 0.f});
+    for (int e = tid * 4; e < 32 * ldcs; e += 1024) st4(wl + e, ld4(c.wslice + e));        // 32 consecutive rows of wcs_t
+    __syncthreads();
+    for (int o8 = og * 8; o8 < ldcs; o8 += 64) {
+        for (int s = 0; s < 2; ++s) {
+            const int n = s ? c.n1 : c.n0;
+            if (n == 0) continue;                     // workgroup-uniform
+            f32x4 p0 = {0.f, 0.f, 0.f, 0.f}, p1 = p0;
+#pragma unroll
+            for (int cb = 0; cb < 8; ++cb) {
+                const f32x4 hv = ld4(hs + s * EPI_TILE + er * EPI_LD + 4 * cb);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float* wp = wl + (4 * cb + k) * ldcs + o8;
+                    const f32x4 w0 = ld4(wp), w1 = ld4(wp + 4);
+#pragma unroll
+                    for (int x = 0; x < 4; ++x) { p0[x] = fmaf(hv[k], w0[x], p0[x]); p1[x] = fmaf(hv[k], w1[x], p1[x]); }
+                }
+            }
+            if (er < n) {
+                float* dst = c.dst + (long long)(32 * s + er) * ldcs + o8;
+                st4_sc1(dst, p0);
+                st4_sc1(dst + 4, p1);
+            }
+        }
+    }
+}
+
+__device__ __forceinline__ HeadsCtx heads_ctx(const SeqArgs& a, int g, int j, int n0, int n1)
+{
+    HeadsCtx c;
+    c.wslice = a.wcs_t + (long long)32 * j * a.ldcs;
+    c.dst = a.hpart + (long long)(g * a.ntiles + j) * 64 * a.ldcs;
+    c.ldcs = a.ldcs; c.n0 = n0; c.n1 = n1;
+    return c;
+}
+
+// PPK_SEQ_TIMING build (tools/seq_timing.py): thread 0 adds the shader-clock cycles of every phase into LDS slots
+#ifdef PPK_SEQ_TIMING
+#define TSTAMP(id) do { if (threadIdx.x == 0) { const long long now_ = __builtin_readcyclecounter(); tacc[id] += now_ - tlast; tlast = now_; } } while (0)
+#else
+#define TSTAMP(id) do { } while (0)
+#endif
+
+struct Step { int n[2]; long long base[2], pbase[2]; };   // active rows, packed row of the slot's first row now / one step earlier
+
+// ---- one GRU layer of one step ------------------------------------------------------------------
+template <int NA>
+__device__ __forceinline__ bool cell(const SeqArgs& a, float* lds, volatile int* flag, const int* r0, const Step& st, int t, int l,
+                                     int g, int j, int wave, int lane, long long* tacc, long long& tlast)
+{
+    const int H = a.H;
+    const int i = 8 * wave + (lane >> 3);                         // row of this lane's DMA piece inside a 32-row block
+    const long long H3 = 3LL * H;
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[s][q][r] = 0.f;
+
+    // part A: W_hh[l] . h_l(t-1)
+    {
+        const float* hp = t > 0 ? a.Hs + (long long)l * a.NT * H : a.h0 + (long long)l * a.B * H;
+        const float* sa[2];
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const int ns = s < NA ? st.n[s] : 1;
+            const int ic = i < ns ? i : ns - 1;
+            const long long row = (t > 0 ? st.pbase[s] : (long long)r0[s]) + ic;
+            sa[s] = dma_src(hp, s < NA ? row : 0, H, i, lane);
+        }
+        const float* w = a.w_hh[l];
+        const int u = 32 * j + i;
+        kloop<NA, 3>(lds, sa[0], sa[1], dma_src(w, u, H, i, lane), dma_src(w, (long long)H + u, H, i, lane),
+                     dma_src(w, 2LL * H + u, H, i, lane), H / BK, acc, wave, lane);
+    }
+    TSTAMP(0);
+    // the input of this layer at this step: the stack top (layer 0) or the layer below
+    int* ctr = a.ctr + (long long)g * (a.L + 1);
+    if (!group_wait(l == 0 ? ctr + a.L : ctr + (l - 1), a.ntiles * (t + 1), a.status, flag)) return false;
+    TSTAMP(1);
+    // part B: W_ih[l] . x_l(t)
+    {
+        const int K = l == 0 ? a.ks : H;
+        const float* xp = l == 0 ? a.XS : a.Hs + (long long)(l - 1) * a.NT * H;
+        const float* sa[2];
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const int ns = s < NA ? st.n[s] : 1;
+            const int ic = i < ns ? i : ns - 1;
+            sa[s] = dma_src(xp, s < NA ? st.base[s] + ic : 0, K, i, lane);
+        }
+        const float* w = l == 0 ? a.wx0s : a.w_ih[l];
+        const int u = 32 * j + i;
+        kloop<NA, 2>(lds, sa[0], sa[1], dma_src(w, u, K, i, lane), dma_src(w, (long long)H + u, K, i, lane),
+                     dma_src(w, 2LL * H + u, K, i, lane), K / BK, acc, wave, lane);
+    }
+    TSTAMP(2);
+    // epilogue: sum the four K-chunk partials in wave order, GRU cell, stores
+    const int li = lane & 31, hh = lane >> 5;
+    const int tid = threadIdx.x, er = tid >> 3, c4 = (tid & 7) * 4, u = 32 * j + c4;
+    f32x4 hout[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+    for (int s = 0; s < NA; ++s) {
+        __syncthreads();                              // staging reads / the previous m-tile's sums are done
+#pragma unroll
+        for (int q = 0; q < 4; ++q) tile_to_lds(lds + (wave * 4 + q) * EPI_TILE, acc[s][q], li, hh);
+        __syncthreads();
+        if (er < st.n[s]) {
+            f32x4 v[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float* p = lds + q * EPI_TILE + er * EPI_LD + c4;
+                v[q] = ld4(p);
+#pragma unroll
+                for (int w = 1; w < 4; ++w) v[q] += ld4(p + w * 4 * EPI_TILE);
+            }
+            const long long row = st.base[s] + er;
+            const float* hprow = (t > 0 ? a.Hs + ((long long)l * a.NT + st.pbase[s] + er) * H
+                                        : a.h0 + ((long long)l * a.B + r0[s] + er) * H) + u;
+            const f32x4 hp = ld4(hprow);
+            // input-side bias: folded into the per-token table for layer 0 (table = emb . W_ih0[:, :E]^T + b_ih0)
+            const float* tp = a.b_ih[l] + u;
+            if (l == 0) {
+                long long tok = a.tokens[row];
+                tok = tok < 0 ? 0 : (tok < a.V ? tok : a.V - 1);
+                tp = a.table + tok * H3 + u;
+            }
+            const float* bp = a.b_hh[l] + u;
+            v[0] += ld4(tp) + ld4(bp);
+            v[1] += ld4(tp + H) + ld4(bp + H);
+            v[2] += ld4(tp + 2 * H);
+            v[3] += ld4(bp + 2 * H);
+            f32x4 rr, zz, nn, ho;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                rr[k] = sigmoidf_(v[0][k]);
+                zz[k] = sigmoidf_(v[1][k]);
+                nn[k] = tanhf(v[2][k] + rr[k] * v[3][k]);
+                ho[k] = (1.0f - zz[k]) * nn[k] + zz[k] * hp[k];
+            }
+            const f32x4 hn = v[3];
+            st4_sc1(a.Hs + ((long long)l * a.NT + row) * H + u, ho);          // handed to the group
+            st4(a.HP + ((long long)l * a.NT + row) * H + u, hp);
+            float* gt = a.gates + ((long long)l * a.NT + row) * 4 * H + u;
+            st4(gt, rr); st4(gt + H, zz); st4(gt + 2 * H, nn); st4(gt + 3 * H, hn);
+            hout[s] = ho;
+        }
+    }
+    if (l == a.L - 1) heads_partial(heads_ctx(a, g, j, st.n[0], NA == 2 ? st.n[1] : 0), lds, hout[0], hout[1]);
+    TSTAMP(3);
+    group_signal(ctr + l);
+    TSTAMP(4);
+    return true;
+}
+
+// ---- stack update of the rows this workgroup owns, for the stack ENTERING step t ----------------
+// (heads = sum of the n-tile partials + bias -> softmax(3) / tanh(W); push / pop / no-op blend of the previous
+// stack row, staged in LDS with 16-byte loads issued together; stack top -> XS, handed to the group)
+struct StackCtx {
+    const float* hpart_g;        // partials of this group: [ntiles][64][ldcs]
+    const float* bcs; const float* Sprev; float* Snew; float* CS; float* XS;     // Sprev / Snew / CS / XS: at this step's first packed row
+    int W, DW, ldcs, ks, rb, ntiles, bt, j, r0a, r0b;
+};
+__device__ __noinline__ void stack_phase(StackCtx c, float* lds)
+{
+    const int W = c.W, DW = c.DW, DW4 = (DW + 3) & ~3, ldcs = c.ldcs, ks = c.ks, tid = threadIdx.x, RB = c.rb;
+    const int nout = 3 + W;
+    const bool vec = (DW & 3) == 0;
+    float* spl = lds;                                 // [RB][DW4]
+    float* act = spl + RB * DW4;                      // [RB][ldcs]
+    float* top = act + RB * ldcs;                     // [RB][ks]
+    // owned group rows: rho = j + k ntiles < 64, in batches of RB; srow = row of the sorted batch
+    auto rowinfo = [&](int rho, long long& srow) -> bool {
+        if (rho >= 64) return false;
+        const int r0 = rho >= 32 ? c.r0b : c.r0a;
+        if (r0 < 0) return false;
+        srow = (long long)r0 + (rho & 31);
+        return srow < c.bt;
+    };
+    for (int rho0 = c.j; rho0 < 64; rho0 += RB * c.ntiles) {
+        bool any = false;
+        for (int k = 0; k < RB; ++k) { long long sr; any = any || rowinfo(rho0 + k * c.ntiles, sr); }
+        if (!any) continue;                           // workgroup-uniform
+        __syncthreads();
+        for (int e = tid; e < RB * ldcs; e += 256) {
+            const int k = e / ldcs, o = e - k * ldcs, rho = rho0 + k * c.ntiles;
+            long long sr;
+            float v = 0.f;
+            if (o < nout && rowinfo(rho, sr)) {
+                const float* pp = c.hpart_g + (long long)rho * ldcs + o;
+                for (int jj = 0; jj < c.ntiles; ++jj)
+                    v += __hip_atomic_load(pp + (long long)jj * 64 * ldcs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                v += c.bcs[o];
+            }
+            act[e] = v;
+        }
+        for (int k = 0; k < RB; ++k) {
+            long long sr;
+            if (!rowinfo(rho0 + k * c.ntiles, sr)) continue;
+            float* dst = spl + k * DW4;
+            if (!c.Sprev) { for (int e = tid; e < DW; e += 256) dst[e] = 0.f; continue; }
+            const float* sp = c.Sprev + sr * DW;
+            if (vec) { for (int e = tid; e < (DW >> 2); e += 256) st4(dst + 4 * e, ld4(sp + 4 * e)); }
+            else { for (int e = tid; e < DW; e += 256) dst[e] = sp[e]; }
+        }
+        __syncthreads();
+        if (tid < RB) {
+            float* r = act + tid * ldcs;
+            const float p0 = r[0], p1 = r[1], p2 = r[2];
+            const float m = fmaxf(p0, fmaxf(p1, p2));
+            const float e0 = expf(p0 - m), e1 = expf(p1 - m), e2 = expf(p2 - m);
+            const float inv = 1.0f / (e0 + e1 + e2);
+            r[0] = e0 * inv; r[1] = e1 * inv; r[2] = e2 * inv;
+        }
+        for (int e = tid; e < RB * ldcs; e += 256) {
+            const int o = e % ldcs;
+            if (o >= 3 && o < nout) act[e] = tanhf(act[e]);
+        }
+        __syncthreads();
+        for (int k = 0; k < RB; ++k) {
+            long long sr;
+            if (!rowinfo(rho0 + k * c.ntiles, sr)) continue;
+            const float* ar = act + k * ldcs;
+            const float* sp = spl + k * DW4;
+            float* cs = c.CS + sr * ldcs;
+            for (int o = tid; o < nout; o += 256) cs[o] = ar[o];
+            const float a_push = ar[0], a_pop = ar[1], a_noop = ar[2];
+            float* sn = c.Snew + sr * DW;
+            auto upd = [&](int e) {
+                const float up = e < W ? ar[3 + e] : sp[e - W];
+                const float down = e + W < DW ? sp[e + W] : 0.f;
+                return a_noop * sp[e] + a_push * up + a_pop * down;
+            };
+            if (vec) {
+                for (int e4 = tid; e4 < (DW >> 2); e4 += 256) {
+                    f32x4 v;
+#pragma unroll
+                    for (int x = 0; x < 4; ++x) v[x] = upd(4 * e4 + x);
+                    st4(sn + 4 * e4, v);
+#pragma unroll
+                    for (int x = 0; x < 4; ++x) if (4 * e4 + x < W) top[k * ks + 4 * e4 + x] = v[x];
+                }
+            } else {
+                for (int e = tid; e < DW; e += 256) {
+                    const float v = upd(e);
+                    sn[e] = v;
+                    if (e < W) top[k * ks + e] = v;
+                }
+            }
+            for (int o = W + tid; o < ks; o += 256) top[k * ks + o] = 0.f;
+        }
+        __syncthreads();
+        for (int e = tid; e < RB * (ks / 4); e += 256) {
+            const int k = e / (ks / 4), o = (e - k * (ks / 4)) * 4;
+            long long sr;
+            if (rowinfo(rho0 + k * c.ntiles, sr)) st4_sc1(c.XS + sr * ks + o, ld4(top + k * ks + o));      // handed to the group
+        }
+    }
+}
+
+__device__ __forceinline__ StackCtx stack_ctx(const SeqArgs& a, const int* r0, const int* off, int t, int g, int j)
+{
+    StackCtx c;
+    const long long DW = (long long)a.D * a.W, ot = off[t], op = t > 0 ? off[t - 1] : 0;
+    c.hpart_g = a.hpart + (long long)g * a.ntiles * 64 * a.ldcs;
+    c.bcs = a.bcs;
+    c.Sprev = t > 0 ? a.S + op * DW : a.S0;
+    c.Snew = a.S + ot * DW;
+    c.CS = a.CS + ot * a.ldcs;
+    c.XS = a.XS + ot * a.ks;
+    c.W = a.W; c.DW = (int)DW; c.ldcs = a.ldcs; c.ks = a.ks; c.rb = a.rb; c.ntiles = a.ntiles; c.bt = a.bs[t]; c.j = j;
+    c.r0a = r0[0]; c.r0b = r0[1];
+    return c;
+}
+__global__ __launch_bounds__(256, 2) void k_seq_fwd(const SeqArgs a)
+{
+    __shared__ __align__(1024) float lds[REGION];
+    __shared__ int off[MAXT + 1];
+    __shared__ int flag;
+    __shared__ long long tacc[8];
+    long long tlast = 0;
+#ifdef PPK_SEQ_TIMING
+    if (threadIdx.x == 0) { for (int k = 0; k < 8; ++k) tacc[k] = 0; tlast = __builtin_readcyclecounter(); }
+#endif
+    // Workgroup ids go round-robin over the 8 XCDs (observed placement; speed only, never correctness).
+    // With >= 8 n-tiles an XCD serves the SAME n-tiles of every group: its weight slice (ntiles / 8 x 96 rows of every
+    // matrix, 1.2 MB at H = 512) stays in its 4 MiB L2, instead of every group streaming all 9.8 MB of weights
+    // through it each step; the hand-off reads (hidden rows, written through to memory anyway) cross XCDs.
+    // With fewer n-tiles a group's workgroups share an XCD.
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    int g, j;
+    if (a.tpx > 0) { g = a.g0 + slot / a.tpx; j = xcd * a.tpx + slot % a.tpx; if (j >= a.ntiles) return; }
+    else { g = a.g0 + (slot / a.ntiles) * 8 + xcd; j = slot % a.ntiles; }
+    if (g >= a.g1) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    if (tid == 0) {
+        int s = 0;
+        for (int t = 0; t < a.T; ++t) { off[t] = s; s += a.bs[t]; }
+        off[a.T] = s;
+    }
+    __syncthreads();
+    const int m1 = 2 * a.G - 1 - g;
+    const int r0[2] = {32 * g, m1 < a.MT && m1 != g ? 32 * m1 : -1};
+    int* ctr = a.ctr + (long long)g * (a.L + 1);
+
+    // "step -1": the heads of the initial hidden state of the top layer
+    {
+        const int er = tid >> 3, c4 = (tid & 7) * 4;
+        int n0[2];
+        f32x4 hv[2];
+        for (int s = 0; s < 2; ++s) {
+            int n = r0[s] >= 0 ? a.B - r0[s] : 0;
+            n0[s] = n < 0 ? 0 : (n > 32 ? 32 : n);
+            hv[s] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (er < n0[s]) hv[s] = ld4(a.h0 + ((long long)(a.L - 1) * a.B + r0[s] + er) * a.H + 32 * j + c4);
+        }
+        heads_partial(heads_ctx(a, g, j, n0[0], n0[1]), lds, hv[0], hv[1]);
+    }
+    group_signal(ctr + (a.L - 1));
+    if (!group_wait(ctr + (a.L - 1), a.ntiles, a.status, &flag)) return;
+    stack_phase(stack_ctx(a, r0, off, 0, g, j), lds);
+    group_signal(ctr + a.L);
+    for (int t = 0; t < a.T; ++t) {
+        const int bt = a.bs[t];
+        if (bt <= r0[0]) break;
+        Step st;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            int n = r0[s] >= 0 ? bt - r0[s] : 0;
+            st.n[s] = n < 0 ? 0 : (n > 32 ? 32 : n);
+            st.base[s] = (long long)off[t] + (r0[s] >= 0 ? r0[s] : 0);
+            st.pbase[s] = (long long)(t > 0 ? off[t - 1] : 0) + (r0[s] >= 0 ? r0[s] : 0);
+        }
+        for (int l = 0; l < a.L; ++l) {
+            const bool ok = st.n[1] > 0 ? cell<2>(a, lds, &flag, r0, st, t, l, g, j, wave, lane, tacc, tlast)
+                                        : cell<1>(a, lds, &flag, r0, st, t, l, g, j, wave, lane, tacc, tlast);
+            if (!ok) return;
+        }
+        if (t + 1 < a.T && a.bs[t + 1] > r0[0]) {
+            if (!group_wait(ctr + (a.L - 1), a.ntiles * (t + 2), a.status, &flag)) return;      // + the "step -1" signal
+            TSTAMP(5);
+            stack_phase(stack_ctx(a, r0, off, t + 1, g, j), lds);
+            TSTAMP(6);
+            group_signal(ctr + a.L);
+            TSTAMP(7);
+        }
+    }
+#ifdef PPK_SEQ_TIMING
+    if (threadIdx.x == 0 && a.dbg) for (int k = 0; k < 8; ++k) a.dbg[(long long)(g * a.ntiles + j) * 8 + k] = tacc[k];
+#endif
+}
+
+// [3+W, H] -> [H, ldcs] (zero padded): the heads read their weights k-major, coalesced over the outputs
+__global__ __launch_bounds__(256) void k_wcs_transpose(const float* __restrict__ wcs, int nout, int H, int ldcs, float* __restrict__ out)
+{
+    const long long total = (long long)H * ldcs;
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+        const int k = (int)(e / ldcs), o = (int)(e - (long long)k * ldcs);
+        out[e] = o < nout ? wcs[(long long)o * H + k] : 0.f;
+    }
+}
+
+long long* g_dbg = nullptr;      // PPK_SEQ_TIMING builds only
+int g_force = -2;                 // -1 auto, 0 never, 1 always (when supported)
+int force_mode()
+{
+    if (g_force == -2) { const char* e = getenv("PPK_SEQ_PERSIST"); g_force = e ? atoi(e) : -1; }
+    return g_force;
+}
+
+}  // namespace
+
+namespace ppk {
+
+int seq_persist_mode(int mode)
+{
+    if (mode >= -1 && mode <= 1) g_force = mode;
+    return force_mode();
+}
+
+bool seq_fwd_persist_ok(int64_t T, int64_t B, int64_t NT, int64_t H, int64_t L, int64_t W, int64_t D, int64_t ks, int64_t ldcs)
+{
+    if (force_mode() == 0) return false;
+    if (T < 1 || T > MAXT || L < 1 || L > MAXL || H % 32 || H > 2048 || ks % 32 || ks > 512 || NT >= (1LL << 31) || B > (1 << 24)) return false;
+    if (ldcs < 3 + W || ldcs % 32) return false;
+    const int64_t DW4 = (D * W + 3) / 4 * 4;
+    if (DW4 + ldcs + ks > REGION) return false;                      // stack-phase scratch: at least one row at a time
+    if (2 * EPI_TILE + 32 * ldcs > REGION) return false;             // heads-partial scratch
+    return true;
+}
+
+size_t seq_fwd_persist_ws_bytes(int64_t B, int64_t H, int64_t L, int64_t W)
+{
+    const int64_t ldcs = (3 + W + 31) / 32 * 32;
+    const int64_t G = ((B + 31) / 32 + 1) / 2;
+    return ppk_align_up(sizeof(float) * (size_t)H * (size_t)ldcs, 256) + ppk_align_up(sizeof(int) * (size_t)(G * (L + 1) + 64), 256)
+           + ppk_align_up(sizeof(float) * (size_t)G * (size_t)(H / 32) * 64 * (size_t)ldcs, 256);
+}
+
+int seq_fwd_persist(int64_t T, const int64_t* bs, int64_t B, int64_t NT, int64_t V, int64_t H, int64_t L, int64_t W, int64_t D,
+                    const int64_t* tokens, const float* table, const float* wx0s, int64_t ks,
+                    const float* const* w_ih, const float* const* w_hh, const float* const* b_ih, const float* const* b_hh,
+                    const float* wcs, const float* bcs, const float* h0, const float* S0,
+                    float* XS, float* Hs, float* HP, float* gates, float* S, float* CS, int64_t ldcs,
+                    void* ws, size_t ws_bytes, hipStream_t stream)
+{
+    if (ws_bytes < seq_fwd_persist_ws_bytes(B, H, L, W)) PPK_FAIL(PPK_ERR_WS, "seq_fwd_persist: workspace too small");
+    SeqArgs a{};
+    a.T = (int)T; a.B = (int)B; a.H = (int)H; a.L = (int)L; a.W = (int)W; a.D = (int)D; a.V = (int)V; a.ks = (int)ks; a.ldcs = (int)ldcs;
+    a.ntiles = (int)(H / 32);
+    a.tpx = a.ntiles >= 8 ? (a.ntiles + 7) / 8 : 0;          // n-tiles per XCD (0: group-major placement)
+    a.MT = (int)((B + 31) / 32);
+    a.G = (a.MT + 1) / 2;
+    a.NT = NT;
+    a.tokens = tokens; a.table = table; a.wx0s = wx0s;
+    for (int l = 0; l < (int)L; ++l) { a.w_ih[l] = w_ih[l]; a.w_hh[l] = w_hh[l]; a.b_ih[l] = b_ih[l]; a.b_hh[l] = b_hh[l]; }
+    a.bcs = bcs; a.h0 = h0; a.S0 = S0;
+    a.dbg = g_dbg;
+    a.XS = XS; a.Hs = Hs; a.HP = HP; a.gates = gates; a.S = S; a.CS = CS;
+    for (int t = 0; t < (int)T; ++t) a.bs[t] = (int)bs[t];
+    char* cur = (char*)ws;
+    float* wcs_t = (float*)ppk_carve(cur, sizeof(float) * (size_t)H * (size_t)ldcs);
+    const size_t nctr = (size_t)a.G * (size_t)(L + 1) + 64;
+    int* ctr = (int*)ppk_carve(cur, sizeof(int) * nctr);
+    a.wcs_t = wcs_t; a.ctr = ctr; a.status = ctr + (size_t)a.G * (size_t)(L + 1);
+    a.hpart = (float*)ppk_carve(cur, sizeof(float) * (size_t)a.G * (size_t)a.ntiles * 64 * (size_t)ldcs);
+    {
+        const int64_t DW4 = (D * W + 3) / 4 * 4;
+        int64_t rb = (REGION) / (DW4 + ldcs + ks);
+        a.rb = (int)(rb > 4 ? 4 : rb);
+    }
+    PPK_HIP(hipMemsetAsync(ctr, 0, sizeof(int) * nctr, stream));
+    k_wcs_transpose<<<dim3((unsigned)std::min<int64_t>((H * ldcs + 255) / 256, 1024)), dim3(256), 0, stream>>>(wcs, (int)(3 + W), (int)H, (int)ldcs, wcs_t);
+    PPK_CHECK_LAUNCH("k_wcs_transpose");
+
+    // every workgroup of a group must be resident together: launch at most one machine-full of groups at a time
+    static int capacity = 0;
+    if (capacity == 0) {
+        int dev = 0, cus = 0, per = 0;
+        PPK_HIP(hipGetDevice(&dev));
+        PPK_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+        PPK_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, k_seq_fwd, 256, 0));
+        capacity = std::max(1, per) * std::max(1, cus);
+    }
+    int groups_per_launch;
+    if (a.tpx > 0) {
+        groups_per_launch = capacity / (8 * a.tpx);                 // grid = 8 tpx workgroups per group (some idle when ntiles % 8 != 0)
+    } else {
+        groups_per_launch = capacity / a.ntiles / 8 * 8;
+        if (groups_per_launch < 8) groups_per_launch = capacity / a.ntiles;      // fewer than 8 groups at a time: still whole groups
+    }
+    if (groups_per_launch < 1) PPK_FAIL(PPK_ERR_UNSUP, "seq_fwd_persist: a group of %d workgroups does not fit the device", a.ntiles);
+    const double flops = 2.0 * (double)NT * 3.0 * (double)H * ((double)ks + (2.0 * (double)L - 1.0) * (double)H);
+    for (int g0 = 0; g0 < a.G; g0 += groups_per_launch) {
+        const int ng = std::min(groups_per_launch, a.G - g0);
+        a.g0 = g0;
+        a.g1 = g0 + ng;
+        const unsigned grid = a.tpx > 0 ? (unsigned)(8 * a.tpx * ng) : (unsigned)(((ng + 7) / 8) * 8 * a.ntiles);
+        ProfScope prof(PK_SEQ_FWD, flops * (double)ng / (double)a.G, stream);
+        k_seq_fwd<<<dim3(grid), dim3(256), 0, stream>>>(a);
+        PPK_CHECK_LAUNCH("k_seq_fwd");
+    }
+    return PPK_OK;
+}
+
+}  // namespace ppk
+
+#ifdef PPK_SEQ_TIMING
+// diagnosis builds only (make EXTRA=-DPPK_SEQ_TIMING; tools/seq_timing.py): [workgroups][8] int64 cycle sums per phase
+extern "C" void ppk_dbg_seq_timing_buffer(long long* p) { g_dbg = p; }
+#endif

@@ -217,7 +217,8 @@ size_t ppk_stackgru_seq_fwd_workspace_bytes(int64_t B, int64_t H, int64_t L, int
 {
     if (B < 1 || H < 1 || L < 1 || W < 1) return 0;
     const int64_t ldcs = (3 + W + 31) / 32 * 32;
-    return (size_t)L * ppk_align_up(sizeof(float) * (size_t)B * 3 * (size_t)H, 256) + ppk_align_up(sizeof(float) * (size_t)B * (size_t)ldcs, 256);
+    return (size_t)L * ppk_align_up(sizeof(float) * (size_t)B * 3 * (size_t)H, 256) + ppk_align_up(sizeof(float) * (size_t)B * (size_t)ldcs, 256)
+           + ppk::seq_fwd_persist_ws_bytes(B, H, L, W);
 }
 
 // table [V, 3H]  = emb . W_ih0[:, :E]^T + b_ih0      (embedding half of the layer-0 input product)
@@ -240,6 +241,10 @@ int ppk_stackgru_seq_fwd(int64_t T, const int64_t* batch_sizes_host, int64_t B, 
     if (!tokens || !table || !wx0s || !w_ih || !w_hh || !b_ih || !b_hh || !wcs || !bcs || !h0 || !XS || !Hs || !HP || !gates || !S || !CS || !workspace)
         PPK_FAIL(PPK_ERR_NULL, "stackgru_seq_fwd: null pointer");
     if (ws_bytes < ppk_stackgru_seq_fwd_workspace_bytes(B, H, L, W)) PPK_FAIL(PPK_ERR_WS, "stackgru_seq_fwd: workspace too small");
+    // the whole time loop as one persistent launch (ppk_seq_persist.hip) when the shape allows it
+    if (ppk::seq_fwd_persist_ok(T, B, NT, H, L, W, D, ks, ldcs))
+        return ppk::seq_fwd_persist(T, batch_sizes_host, B, NT, V, H, L, W, D, tokens, table, wx0s, ks, w_ih, w_hh, b_ih, b_hh,
+                                    wcs, bcs, h0, S0, XS, Hs, HP, gates, S, CS, ldcs, workspace, ws_bytes, stream);
     char* cur = (char*)workspace;
     std::vector<float*> gh((size_t)L);
     for (int64_t l = 0; l < L; ++l) gh[(size_t)l] = (float*)ppk_carve(cur, sizeof(float) * (size_t)B * 3 * H);
@@ -383,5 +388,9 @@ int ppk_stackgru_seq_bwd(int64_t T, const int64_t* batch_sizes_host, int64_t B, 
     const ppk::NtProblem p = nt_store(DCS, ldcs, B, wcs_t, ldcs, H, ldcs, dh0 + (L - 1) * B * H, H, nullptr, 1.f, H);
     return ppk::gemm_nt64(&p, 1, stream);
 }
+
+// Test / tuning hook: -1 = the persistent sequence kernels run whenever the shape allows (default), 0 = never
+// (per-timestep launches), 1 = same as -1; any other value only queries.  Returns the value in force.
+int ppk_seq_persist_mode(int mode) { return ppk::seq_persist_mode(mode); }
 
 }  // extern "C"

@@ -14,7 +14,7 @@ import os
 import torch  # noqa: F401
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libppk.so')
+LIB_PATH = os.environ.get('PPK_LIB_PATH') or os.path.join(_HERE, 'libppk.so')      # PPK_LIB_PATH: instrumented builds (tools/)
 
 c_i64 = ctypes.c_int64
 c_int = ctypes.c_int

@@ -44,10 +44,12 @@ constexpr int BK = 32;
 constexpr int MAXT = ppk::SEQP_MAXT, MAXL = ppk::SEQP_MAXL;
 constexpr int STG_BUF = 5 * 1024;              // floats per staging buffer: A slot 0, A slot 1, B r, B z, B n (32 x 32 each)
 constexpr int NBUF = 3;
-constexpr int EPI_LD = 36;                     // floats per transposed row (16-B aligned, bank-friendly)
+constexpr int EPI_LD = 32;                     // floats per transposed row: a thread reads (row = tid / 8, 4 columns), so every
+                                               // 16-lane read group covers 256 contiguous bytes without padding
 constexpr int EPI_TILE = 32 * EPI_LD;
 constexpr int REGION = 4 * 4 * EPI_TILE;       // floats: 4 waves x 4 accumulators, transposed (also staging / stack scratch)
 constexpr int SPIN_LIMIT = 1 << 22;            // polls of ~0.3 us: > 1 s
+constexpr int WL_MAX = 32 * 64;                // floats: this workgroup's slice of the transposed head weights (ldcs <= 64)
 static_assert(NBUF * STG_BUF <= REGION, "staging fits the shared region");
 
 #define PPK_LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
@@ -73,11 +75,37 @@ template <int N> __device__ __forceinline__ void wait_vmcnt()
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 __device__ __forceinline__ void st4(float* p, const f32x4& v) { *reinterpret_cast<f32x4*>(p) = v; }
-// write-through 16-byte store (sc1): the bytes are at the coherence point once the wave's vmcnt drains
-__device__ __forceinline__ void st4_sc1(float* p, const f32x4& v)
+// Write-through / L1-bypassing 16-byte accesses of hand-off data (cache policy sc1) as raw buffer instructions:
+// base = a wave-uniform pointer, byte_off = this lane's offset (< 2 GiB).  The compiler counts them in vmcnt itself.
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+constexpr int CPOL_SC1 = 16;
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const float* base)
 {
-    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+    return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, 0x7fffffff, 0x00020000);
 }
+__device__ __forceinline__ void st4_sc1(const float* base, long long byte_off, const f32x4& v)
+{
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), make_rsrc(base), (int)byte_off, 0, CPOL_SC1);
+}
+__device__ __forceinline__ f32x4 ld4_sc1(const float* base, long long byte_off)
+{
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(make_rsrc(base), (int)byte_off, 0, CPOL_SC1));
+}
+
+// LDS of the kernel (file scope so that the non-inlined phases address it with DS instructions, not through flat pointers)
+__shared__ __align__(1024) float g_lds[REGION];      // staging buffers | transposed accumulator partials | stack-phase scratch
+__shared__ __align__(16) float g_wl[WL_MAX];         // rows 32 j .. 32 j + 31 of wcs_t [H, ldcs]: constant for the workgroup
+__shared__ int g_off[MAXT + 1];
+__shared__ int g_flag;
+__shared__ long long g_tacc[16];
+__shared__ long long g_tlast;
+
+// PPK_SEQ_TIMING build (tools/seq_timing.py): thread 0 adds the shader-clock cycles of every phase into LDS slots
+#ifdef PPK_SEQ_TIMING
+#define TSTAMP(id) do { if (threadIdx.x == 0) { const long long now_ = __builtin_readcyclecounter(); g_tacc[id] += now_ - g_tlast; g_tlast = now_; } } while (0)
+#else
+#define TSTAMP(id) do { } while (0)
+#endif
 
 // ---- group-local synchronisation ----------------------------------------------------------
 // every wave has drained its stores -> barrier -> one counter add
@@ -174,16 +202,15 @@ __device__ __forceinline__ const float* dma_src(const float* base, long long row
 //   hpart [(g ntiles + j) 64 + 32 slot + row][ldcs]      (rewritten every step: write-through stores, sc1 loads behind
 //                                                          the acquire on the reading side)
 // (noinline, called while no accumulator is live; small by-value context: the 2.5 KB argument block stays in the kernarg segment)
-struct HeadsCtx { const float* wslice; float* dst; int ldcs, n0, n1; };
-__device__ __noinline__ void heads_partial(HeadsCtx c, float* lds, f32x4 ho0, f32x4 ho1)
+struct HeadsCtx { float* dst; int ldcs, n0, n1; };
+__device__ __noinline__ void heads_partial(HeadsCtx c, f32x4 ho0, f32x4 ho1)
 {
     const int tid = threadIdx.x, er = tid >> 3, c4 = (tid & 7) * 4, og = tid & 7, ldcs = c.ldcs;
-    float* hs = lds;                                  // [2][32][EPI_LD]
-    float* wl = lds + 2 * EPI_TILE;                   // [32][ldcs]
+    float* hs = g_lds;                                // [2][32][36]
+    constexpr int HS_LD = 36, HS_TILE = 32 * HS_LD;
     __syncthreads();                                  // the partial sums of the last m-tile have been read
-    st4(hs + er * EPI_LD + c4, er < c.n0 ? ho0 : f32x4{0.f, 0.f, 0.f, 0.f});
-    st4(hs + EPI_TILE + er * EPI_LD + c4, er < c.n1 ? ho1 : f32x4{0.f, 0.f, 0.f, 0.f});
-    for (int e = tid * 4; e < 32 * ldcs; e += 1024) st4(wl + e, ld4(c.wslice + e));        // 32 consecutive rows of wcs_t
+    st4(hs + er * HS_LD + c4, er < c.n0 ? ho0 : f32x4{0.f, 0.f, 0.f, 0.f});
+    st4(hs + HS_TILE + er * HS_LD + c4, er < c.n1 ? ho1 : f32x4{0.f, 0.f, 0.f, 0.f});
     __syncthreads();
     for (int o8 = og * 8; o8 < ldcs; o8 += 64) {
         for (int s = 0; s < 2; ++s) {
@@ -192,19 +219,19 @@ __device__ __noinline__ void heads_partial(HeadsCtx c, float* lds, f32x4 ho0, f3
             f32x4 p0 = {0.f, 0.f, 0.f, 0.f}, p1 = p0;
 #pragma unroll
             for (int cb = 0; cb < 8; ++cb) {
-                const f32x4 hv = ld4(hs + s * EPI_TILE + er * EPI_LD + 4 * cb);
+                const f32x4 hv = ld4(hs + s * HS_TILE + er * HS_LD + 4 * cb);
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
-                    const float* wp = wl + (4 * cb + k) * ldcs + o8;
+                    const float* wp = g_wl + (4 * cb + k) * ldcs + o8;
                     const f32x4 w0 = ld4(wp), w1 = ld4(wp + 4);
 #pragma unroll
                     for (int x = 0; x < 4; ++x) { p0[x] = fmaf(hv[k], w0[x], p0[x]); p1[x] = fmaf(hv[k], w1[x], p1[x]); }
                 }
             }
             if (er < n) {
-                float* dst = c.dst + (long long)(32 * s + er) * ldcs + o8;
-                st4_sc1(dst, p0);
-                st4_sc1(dst + 4, p1);
+                const long long off = ((long long)(32 * s + er) * ldcs + o8) * 4;
+                st4_sc1(c.dst, off, p0);
+                st4_sc1(c.dst, off + 16, p1);
             }
         }
     }
@@ -213,18 +240,10 @@ __device__ __noinline__ void heads_partial(HeadsCtx c, float* lds, f32x4 ho0, f3
 __device__ __forceinline__ HeadsCtx heads_ctx(const SeqArgs& a, int g, int j, int n0, int n1)
 {
     HeadsCtx c;
-    c.wslice = a.wcs_t + (long long)32 * j * a.ldcs;
     c.dst = a.hpart + (long long)(g * a.ntiles + j) * 64 * a.ldcs;
     c.ldcs = a.ldcs; c.n0 = n0; c.n1 = n1;
     return c;
 }
-
-// PPK_SEQ_TIMING build (tools/seq_timing.py): thread 0 adds the shader-clock cycles of every phase into LDS slots
-#ifdef PPK_SEQ_TIMING
-#define TSTAMP(id) do { if (threadIdx.x == 0) { const long long now_ = __builtin_readcyclecounter(); tacc[id] += now_ - tlast; tlast = now_; } } while (0)
-#else
-#define TSTAMP(id) do { } while (0)
-#endif
 
 struct Step { int n[2]; long long base[2], pbase[2]; };   // active rows, packed row of the slot's first row now / one step earlier
 
@@ -236,6 +255,17 @@ __device__ __forceinline__ bool cell(const SeqArgs& a, float* lds, volatile int*
     const int H = a.H;
     const int i = 8 * wave + (lane >> 3);                         // row of this lane's DMA piece inside a 32-row block
     const long long H3 = 3LL * H;
+    // token of this thread's epilogue row (layer 0 looks its input-side pre-activations up in the [V, 3H] table):
+    // fetched now, long before the table address is needed
+    int tokv[2] = {0, 0};
+    if (l == 0) {
+#pragma unroll
+        for (int s = 0; s < NA; ++s)
+            if ((int)(threadIdx.x >> 3) < st.n[s]) {
+                long long tok = a.tokens[st.base[s] + (threadIdx.x >> 3)];
+                tokv[s] = (int)(tok < 0 ? 0 : (tok < a.V ? tok : a.V - 1));
+            }
+    }
     f32x16 acc[2][4];
 #pragma unroll
     for (int s = 0; s < 2; ++s)
@@ -288,6 +318,18 @@ __device__ __forceinline__ bool cell(const SeqArgs& a, float* lds, volatile int*
     f32x4 hout[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
     for (int s = 0; s < NA; ++s) {
+        // epilogue operands of this m-tile: issued before the transposition so that their latency hides behind it
+        // (input-side bias: folded into the per-token table for layer 0, table = emb . W_ih0[:, :E]^T + b_ih0)
+        f32x4 hp = {0.f, 0.f, 0.f, 0.f}, pf[6];
+#pragma unroll
+        for (int q = 0; q < 6; ++q) pf[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (er < st.n[s]) {
+            hp = ld4((t > 0 ? a.Hs + ((long long)l * a.NT + st.pbase[s] + er) * H : a.h0 + ((long long)l * a.B + r0[s] + er) * H) + u);
+            const float* tp = l == 0 ? a.table + (long long)tokv[s] * H3 + u : a.b_ih[l] + u;
+            const float* bp = a.b_hh[l] + u;
+            pf[0] = ld4(tp); pf[1] = ld4(tp + H); pf[2] = ld4(tp + 2 * H);
+            pf[3] = ld4(bp); pf[4] = ld4(bp + H); pf[5] = ld4(bp + 2 * H);
+        }
         __syncthreads();                              // staging reads / the previous m-tile's sums are done
 #pragma unroll
         for (int q = 0; q < 4; ++q) tile_to_lds(lds + (wave * 4 + q) * EPI_TILE, acc[s][q], li, hh);
@@ -302,21 +344,10 @@ __device__ __forceinline__ bool cell(const SeqArgs& a, float* lds, volatile int*
                 for (int w = 1; w < 4; ++w) v[q] += ld4(p + w * 4 * EPI_TILE);
             }
             const long long row = st.base[s] + er;
-            const float* hprow = (t > 0 ? a.Hs + ((long long)l * a.NT + st.pbase[s] + er) * H
-                                        : a.h0 + ((long long)l * a.B + r0[s] + er) * H) + u;
-            const f32x4 hp = ld4(hprow);
-            // input-side bias: folded into the per-token table for layer 0 (table = emb . W_ih0[:, :E]^T + b_ih0)
-            const float* tp = a.b_ih[l] + u;
-            if (l == 0) {
-                long long tok = a.tokens[row];
-                tok = tok < 0 ? 0 : (tok < a.V ? tok : a.V - 1);
-                tp = a.table + tok * H3 + u;
-            }
-            const float* bp = a.b_hh[l] + u;
-            v[0] += ld4(tp) + ld4(bp);
-            v[1] += ld4(tp + H) + ld4(bp + H);
-            v[2] += ld4(tp + 2 * H);
-            v[3] += ld4(bp + 2 * H);
+            v[0] += pf[0] + pf[3];
+            v[1] += pf[1] + pf[4];
+            v[2] += pf[2];
+            v[3] += pf[5];
             f32x4 rr, zz, nn, ho;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
@@ -326,14 +357,15 @@ __device__ __forceinline__ bool cell(const SeqArgs& a, float* lds, volatile int*
                 ho[k] = (1.0f - zz[k]) * nn[k] + zz[k] * hp[k];
             }
             const f32x4 hn = v[3];
-            st4_sc1(a.Hs + ((long long)l * a.NT + row) * H + u, ho);          // handed to the group
+            st4_sc1(a.Hs + ((long long)l * a.NT + st.base[s]) * H, ((long long)er * H + u) * 4, ho);      // handed to the group
             st4(a.HP + ((long long)l * a.NT + row) * H + u, hp);
             float* gt = a.gates + ((long long)l * a.NT + row) * 4 * H + u;
             st4(gt, rr); st4(gt + H, zz); st4(gt + 2 * H, nn); st4(gt + 3 * H, hn);
             hout[s] = ho;
         }
     }
-    if (l == a.L - 1) heads_partial(heads_ctx(a, g, j, st.n[0], NA == 2 ? st.n[1] : 0), lds, hout[0], hout[1]);
+    TSTAMP(13);
+    if (l == a.L - 1) heads_partial(heads_ctx(a, g, j, st.n[0], NA == 2 ? st.n[1] : 0), hout[0], hout[1]);
     TSTAMP(3);
     group_signal(ctr + l);
     TSTAMP(4);
@@ -348,8 +380,9 @@ struct StackCtx {
     const float* bcs; const float* Sprev; float* Snew; float* CS; float* XS;     // Sprev / Snew / CS / XS: at this step's first packed row
     int W, DW, ldcs, ks, rb, ntiles, bt, j, r0a, r0b;
 };
-__device__ __noinline__ void stack_phase(StackCtx c, float* lds)
+__device__ __noinline__ void stack_phase(StackCtx c)
 {
+    float* lds = g_lds;
     const int W = c.W, DW = c.DW, DW4 = (DW + 3) & ~3, ldcs = c.ldcs, ks = c.ks, tid = threadIdx.x, RB = c.rb;
     const int nout = 3 + W;
     const bool vec = (DW & 3) == 0;
@@ -369,28 +402,68 @@ __device__ __noinline__ void stack_phase(StackCtx c, float* lds)
         for (int k = 0; k < RB; ++k) { long long sr; any = any || rowinfo(rho0 + k * c.ntiles, sr); }
         if (!any) continue;                           // workgroup-uniform
         __syncthreads();
-        for (int e = tid; e < RB * ldcs; e += 256) {
-            const int k = e / ldcs, o = e - k * ldcs, rho = rho0 + k * c.ntiles;
+        // heads = partials of the ntiles workgroups added in tile order + bias; ntiles independent 16-byte loads per thread
+        for (int e = tid; e < RB * (ldcs >> 2); e += 256) {
+            const int k = e / (ldcs >> 2), o = (e - k * (ldcs >> 2)) * 4, rho = rho0 + k * c.ntiles;
             long long sr;
-            float v = 0.f;
-            if (o < nout && rowinfo(rho, sr)) {
-                const float* pp = c.hpart_g + (long long)rho * ldcs + o;
-                for (int jj = 0; jj < c.ntiles; ++jj)
-                    v += __hip_atomic_load(pp + (long long)jj * 64 * ldcs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                v += c.bcs[o];
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (rowinfo(rho, sr)) {
+                const long long b0 = ((long long)rho * ldcs + o) * 4;
+                for (int j0 = 0; j0 < c.ntiles; j0 += 16) {         // sixteen loads in flight (one memory round trip), added in tile order
+                    f32x4 p[16];
+#pragma unroll
+                    for (int x = 0; x < 16; ++x) {
+                        const int jj = j0 + x < c.ntiles ? j0 + x : c.ntiles - 1;
+                        p[x] = ld4_sc1(c.hpart_g, b0 + (long long)jj * 64 * ldcs * 4);
+                    }
+#pragma unroll
+                    for (int x = 0; x < 16; ++x) if (j0 + x < c.ntiles) v += p[x];
+                }
+#pragma unroll
+                for (int x = 0; x < 4; ++x) v[x] = o + x < nout ? v[x] + c.bcs[o + x] : 0.f;
             }
-            act[e] = v;
+            st4(act + k * ldcs + o, v);
         }
-        for (int k = 0; k < RB; ++k) {
-            long long sr;
-            if (!rowinfo(rho0 + k * c.ntiles, sr)) continue;
-            float* dst = spl + k * DW4;
-            if (!c.Sprev) { for (int e = tid; e < DW; e += 256) dst[e] = 0.f; continue; }
-            const float* sp = c.Sprev + sr * DW;
-            if (vec) { for (int e = tid; e < (DW >> 2); e += 256) st4(dst + 4 * e, ld4(sp + 4 * e)); }
-            else { for (int e = tid; e < DW; e += 256) dst[e] = sp[e]; }
+        // previous stack rows -> LDS: the loads of all rows are issued together (up to 16 x 16 bytes in flight per thread)
+        {
+            const float* sp[4];
+            bool on[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                long long sr = 0;
+                on[k] = k < RB && rowinfo(rho0 + k * c.ntiles, sr);
+                sp[k] = c.Sprev ? c.Sprev + sr * DW : nullptr;
+            }
+            if (!c.Sprev) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) if (on[k]) for (int e = tid; e < DW; e += 256) spl[k * DW4 + e] = 0.f;
+            } else if (vec) {
+                const int n4 = DW >> 2;
+                for (int e0 = 0; e0 < n4; e0 += 4 * 256) {
+                    f32x4 tmp[4][4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+#pragma unroll
+                        for (int x = 0; x < 4; ++x) {
+                            const int e = e0 + x * 256 + tid;
+                            if (on[k] && e < n4) tmp[k][x] = ld4(sp[k] + 4 * e);
+                        }
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+#pragma unroll
+                        for (int x = 0; x < 4; ++x) {
+                            const int e = e0 + x * 256 + tid;
+                            if (on[k] && e < n4) st4(spl + k * DW4 + 4 * e, tmp[k][x]);
+                        }
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) if (on[k]) for (int e = tid; e < DW; e += 256) spl[k * DW4 + e] = sp[k][e];
+            }
         }
+        TSTAMP(8);
         __syncthreads();
+        TSTAMP(9);
         if (tid < RB) {
             float* r = act + tid * ldcs;
             const float p0 = r[0], p1 = r[1], p2 = r[2];
@@ -404,6 +477,7 @@ __device__ __noinline__ void stack_phase(StackCtx c, float* lds)
             if (o >= 3 && o < nout) act[e] = tanhf(act[e]);
         }
         __syncthreads();
+        TSTAMP(10);
         for (int k = 0; k < RB; ++k) {
             long long sr;
             if (!rowinfo(rho0 + k * c.ntiles, sr)) continue;
@@ -436,11 +510,13 @@ __device__ __noinline__ void stack_phase(StackCtx c, float* lds)
             }
             for (int o = W + tid; o < ks; o += 256) top[k * ks + o] = 0.f;
         }
+        TSTAMP(11);
         __syncthreads();
+        TSTAMP(12);
         for (int e = tid; e < RB * (ks / 4); e += 256) {
             const int k = e / (ks / 4), o = (e - k * (ks / 4)) * 4;
             long long sr;
-            if (rowinfo(rho0 + k * c.ntiles, sr)) st4_sc1(c.XS + sr * ks + o, ld4(top + k * ks + o));      // handed to the group
+            if (rowinfo(rho0 + k * c.ntiles, sr)) st4_sc1(c.XS, (sr * ks + o) * 4, ld4(top + k * ks + o));      // handed to the group
         }
     }
 }
@@ -461,13 +537,12 @@ __device__ __forceinline__ StackCtx stack_ctx(const SeqArgs& a, const int* r0, c
 }
 __global__ __launch_bounds__(256, 2) void k_seq_fwd(const SeqArgs a)
 {
-    __shared__ __align__(1024) float lds[REGION];
-    __shared__ int off[MAXT + 1];
-    __shared__ int flag;
-    __shared__ long long tacc[8];
+    float* lds = g_lds;
+    int* off = g_off;
+    long long* tacc = g_tacc;
     long long tlast = 0;
 #ifdef PPK_SEQ_TIMING
-    if (threadIdx.x == 0) { for (int k = 0; k < 8; ++k) tacc[k] = 0; tlast = __builtin_readcyclecounter(); }
+    if (threadIdx.x == 0) { for (int k = 0; k < 16; ++k) g_tacc[k] = 0; g_tlast = __builtin_readcyclecounter(); }
 #endif
     // Workgroup ids go round-robin over the 8 XCDs (observed placement; speed only, never correctness).
     // With >= 8 n-tiles an XCD serves the SAME n-tiles of every group: its weight slice (ntiles / 8 x 96 rows of every
@@ -485,6 +560,7 @@ __global__ __launch_bounds__(256, 2) void k_seq_fwd(const SeqArgs a)
         for (int t = 0; t < a.T; ++t) { off[t] = s; s += a.bs[t]; }
         off[a.T] = s;
     }
+    for (int e = tid * 4; e < 32 * a.ldcs; e += 1024) st4(g_wl + e, ld4(a.wcs_t + (long long)32 * j * a.ldcs + e));
     __syncthreads();
     const int m1 = 2 * a.G - 1 - g;
     const int r0[2] = {32 * g, m1 < a.MT && m1 != g ? 32 * m1 : -1};
@@ -501,11 +577,11 @@ __global__ __launch_bounds__(256, 2) void k_seq_fwd(const SeqArgs a)
             hv[s] = f32x4{0.f, 0.f, 0.f, 0.f};
             if (er < n0[s]) hv[s] = ld4(a.h0 + ((long long)(a.L - 1) * a.B + r0[s] + er) * a.H + 32 * j + c4);
         }
-        heads_partial(heads_ctx(a, g, j, n0[0], n0[1]), lds, hv[0], hv[1]);
+        heads_partial(heads_ctx(a, g, j, n0[0], n0[1]), hv[0], hv[1]);
     }
     group_signal(ctr + (a.L - 1));
-    if (!group_wait(ctr + (a.L - 1), a.ntiles, a.status, &flag)) return;
-    stack_phase(stack_ctx(a, r0, off, 0, g, j), lds);
+    if (!group_wait(ctr + (a.L - 1), a.ntiles, a.status, &g_flag)) return;
+    stack_phase(stack_ctx(a, r0, off, 0, g, j));
     group_signal(ctr + a.L);
     for (int t = 0; t < a.T; ++t) {
         const int bt = a.bs[t];
@@ -519,21 +595,21 @@ __global__ __launch_bounds__(256, 2) void k_seq_fwd(const SeqArgs a)
             st.pbase[s] = (long long)(t > 0 ? off[t - 1] : 0) + (r0[s] >= 0 ? r0[s] : 0);
         }
         for (int l = 0; l < a.L; ++l) {
-            const bool ok = st.n[1] > 0 ? cell<2>(a, lds, &flag, r0, st, t, l, g, j, wave, lane, tacc, tlast)
-                                        : cell<1>(a, lds, &flag, r0, st, t, l, g, j, wave, lane, tacc, tlast);
+            const bool ok = st.n[1] > 0 ? cell<2>(a, lds, &g_flag, r0, st, t, l, g, j, wave, lane, tacc, tlast)
+                                        : cell<1>(a, lds, &g_flag, r0, st, t, l, g, j, wave, lane, tacc, tlast);
             if (!ok) return;
         }
         if (t + 1 < a.T && a.bs[t + 1] > r0[0]) {
-            if (!group_wait(ctr + (a.L - 1), a.ntiles * (t + 2), a.status, &flag)) return;      // + the "step -1" signal
+            if (!group_wait(ctr + (a.L - 1), a.ntiles * (t + 2), a.status, &g_flag)) return;      // + the "step -1" signal
             TSTAMP(5);
-            stack_phase(stack_ctx(a, r0, off, t + 1, g, j), lds);
+            stack_phase(stack_ctx(a, r0, off, t + 1, g, j));
             TSTAMP(6);
             group_signal(ctr + a.L);
             TSTAMP(7);
         }
     }
 #ifdef PPK_SEQ_TIMING
-    if (threadIdx.x == 0 && a.dbg) for (int k = 0; k < 8; ++k) a.dbg[(long long)(g * a.ntiles + j) * 8 + k] = tacc[k];
+    if (threadIdx.x == 0 && a.dbg) for (int k = 0; k < 16; ++k) a.dbg[(long long)(g * a.ntiles + j) * 16 + k] = g_tacc[k];
 #endif
 }
 
@@ -572,7 +648,7 @@ bool seq_fwd_persist_ok(int64_t T, int64_t B, int64_t NT, int64_t H, int64_t L, 
     if (ldcs < 3 + W || ldcs % 32) return false;
     const int64_t DW4 = (D * W + 3) / 4 * 4;
     if (DW4 + ldcs + ks > REGION) return false;                      // stack-phase scratch: at least one row at a time
-    if (2 * EPI_TILE + 32 * ldcs > REGION) return false;             // heads-partial scratch
+    if (32 * ldcs > WL_MAX) return false;                            // the head-weight slice kept in LDS
     return true;
 }
 

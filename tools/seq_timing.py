@@ -13,7 +13,8 @@ import bench  # noqa: E402
 from paccmann_polymer_amd import _C  # noqa: E402
 from paccmann_polymer_amd.paccmann_encoder import Encoder  # noqa: E402
 
-names = ['kloop A', 'wait input', 'kloop B', 'epilogue', 'signal', 'wait top', 'stack phase', 'signal S']
+names = ['kloop A', 'wait input', 'kloop B', 'heads partial', 'signal', 'wait top', 'stack: XS store', 'signal S',
+         'stack: loads', 'stack: sync', 'stack: act', 'stack: update', 'stack: sync2', 'epilogue', '-', '-']
 lib = _C.lib
 lib.ppk_dbg_seq_timing_buffer.argtypes = [ctypes.c_void_p]
 rng = np.random.default_rng(1234)
@@ -24,7 +25,7 @@ torch.manual_seed(0)
 model = Encoder(bench.PARAMS, None, None, batch_size=1, batch_mode='Packed')
 G = ((B + 31) // 32 + 1) // 2
 nwg = G * 16
-buf = torch.zeros(nwg * 8, dtype=torch.int64, device='cuda')
+buf = torch.zeros(nwg * 16, dtype=torch.int64, device='cuda')
 with torch.no_grad():
     for it in range(3):
         buf.zero_()
@@ -36,7 +37,7 @@ with torch.no_grad():
         ev1.record()
         torch.cuda.synchronize()
         ms = ev0.elapsed_time(ev1)
-t = buf.view(nwg, 8).double().cpu().numpy()
+t = buf.view(nwg, 16).double().cpu().numpy()
 tot = t.sum(1)
 print(f'encode forward {ms:.3f} ms, T = {enc.batch_sizes.numel()}, workgroups {nwg}; cycles per workgroup: mean {tot.mean():.3e} max {tot.max():.3e}')
 for k, n in enumerate(names):

@@ -193,7 +193,7 @@ int ppk_stackgru_seq_fwd(int64_t T, const int64_t* batch_sizes_host, int64_t B, 
  * The backward takes the weights TRANSPOSED (host arrays of L device pointers:
  * w_ih_t[0] [W, 3H] = stack columns of weight_ih_l0, w_ih_t[l>=1] [H, 3H], w_hh_t[l] [H, 3H];
  * wcs_t [H, ldcs] zero padded) so that the per-step data-gradient GEMMs read k-contiguous operands. */
-size_t ppk_stackgru_seq_bwd_workspace_bytes(int64_t B, int64_t W, int64_t D);
+size_t ppk_stackgru_seq_bwd_workspace_bytes(int64_t B, int64_t H, int64_t L, int64_t W, int64_t D);
 int ppk_stackgru_seq_bwd(int64_t T, const int64_t* batch_sizes_host, int64_t B, int64_t NT,
                          int64_t H, int64_t L, int64_t W, int64_t D,
                          const float* const* w_ih_t, const float* const* w_hh_t, const float* wcs_t,

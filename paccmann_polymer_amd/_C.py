@@ -50,7 +50,7 @@ SIGNATURES = {
     'ppk_stackgru_seq_fwd': (c_int, [c_i64, ptr, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64,
                                      ptr, ptr, ptr, c_i64, ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr,
                                      ptr, ptr, ptr, ptr, ptr, ptr, c_i64, ptr, c_sz, ptr]),
-    'ppk_stackgru_seq_bwd_workspace_bytes': (c_sz, [c_i64, c_i64, c_i64]),
+    'ppk_stackgru_seq_bwd_workspace_bytes': (c_sz, [c_i64, c_i64, c_i64, c_i64, c_i64]),
     'ppk_stackgru_seq_bwd': (c_int, [c_i64, ptr, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64,
                                      ptr, ptr, ptr, ptr, ptr, ptr, ptr, c_i64,
                                      ptr, ptr, c_i64, ptr, ptr, ptr, ptr, ptr, c_sz, ptr]),

@@ -51,6 +51,14 @@ int seq_fwd_persist(int64_t T, const int64_t* bs, int64_t B, int64_t NT, int64_t
                     float* XS, float* Hs, float* HP, float* gates, float* S, float* CS, int64_t ldcs,
                     void* ws, size_t ws_bytes, hipStream_t stream);
 
+bool seq_bwd_persist_ok(int64_t T, int64_t B, int64_t NT, int64_t H, int64_t L, int64_t W, int64_t D, int64_t ks, int64_t ldcs);
+size_t seq_bwd_persist_ws_bytes(int64_t B, int64_t H, int64_t L, int64_t W, int64_t D);
+int seq_bwd_persist(int64_t T, const int64_t* bs, int64_t B, int64_t NT, int64_t H, int64_t L, int64_t W, int64_t D,
+                    const float* const* w_ih_t, const float* const* w_hh_t, const float* wcs_t,
+                    const float* HP, const float* gates, const float* S, const float* CS, int64_t ldcs,
+                    const float* dHtop, float* dXS, int64_t ks, float* DGI, float* DGH, float* DCS, float* dh0,
+                    void* ws, size_t ws_bytes, hipStream_t stream);
+
 // ---- opt-in per-kernel timing (HIP events on the launch stream) -------------
 // Off by default; bench.py switches it on for ONE extra step after the timed
 // region to price each kernel family against its roofline.

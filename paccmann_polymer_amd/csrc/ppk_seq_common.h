@@ -1,0 +1,90 @@
+// Device helpers shared by the persistent StackGRU sequence kernels (ppk_seq_persist.hip forward,
+// ppk_seq_persist_bwd.hip backward): 16-byte accesses, write-through / L1-bypassing hand-off accesses (cache policy
+// sc1) as raw buffer instructions, the group-local signal / wait pair, accumulator transposition, LDS-DMA sources.
+//
+// Cross-workgroup hand-offs follow MI355X_MICROARCH.md's valid forms: producer = write-through (sc1) 16-byte stores,
+// every wave drains vmcnt, workgroup barrier, ONE agent-scope counter add; consumer = ONE lane polls (relaxed, agent),
+// agent acquire (buffer_inv sc1), vmcnt(0), workgroup barrier, then plain loads / LDS-DMA (sc1 loads where a buffer is
+// rewritten every step).  Polls are bounded: on a timeout the kernel raises a status word and every workgroup leaves.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace ppk_seq {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int BK = 32;
+constexpr int EPI_LD = 32;                     // floats per transposed accumulator row: a thread reads (row = tid / 8, 4 columns), so
+                                               // every 16-lane read group covers 256 contiguous bytes without padding
+constexpr int EPI_TILE = 32 * EPI_LD;
+constexpr int SPIN_LIMIT = 1 << 22;            // polls of ~0.5 us: seconds
+#define PPK_LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
+
+template <int N> __device__ __forceinline__ void wait_vmcnt()
+{
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+__device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+__device__ __forceinline__ void st4(float* p, const f32x4& v) { *reinterpret_cast<f32x4*>(p) = v; }
+// Write-through / L1-bypassing 16-byte accesses of hand-off data (cache policy sc1) as raw buffer instructions:
+// base = a wave-uniform pointer, byte_off = this lane's offset (< 2 GiB).  The compiler counts them in vmcnt itself.
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+constexpr int CPOL_SC1 = 16;
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const float* base)
+{
+    return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, 0x7fffffff, 0x00020000);
+}
+__device__ __forceinline__ void st4_sc1(const float* base, long long byte_off, const f32x4& v)
+{
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), make_rsrc(base), (int)byte_off, 0, CPOL_SC1);
+}
+__device__ __forceinline__ f32x4 ld4_sc1(const float* base, long long byte_off)
+{
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(make_rsrc(base), (int)byte_off, 0, CPOL_SC1));
+}
+
+// ---- group-local synchronisation ----------------------------------------------------------
+// every wave has drained its stores -> barrier -> one counter add
+__device__ __forceinline__ void group_signal(int* ctr)
+{
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_fetch_add(ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// one lane polls, acquires, then the workgroup barrier; false = timeout / another workgroup gave up
+__device__ __forceinline__ bool group_wait(int* ctr, int target, int* status, volatile int* flag)
+{
+    if (threadIdx.x == 0) {
+        int ok = 0;
+        for (int it = 0; it < SPIN_LIMIT; ++it) {
+            if (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target) { ok = 1; break; }
+            if ((it & 255) == 255 && __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
+            __builtin_amdgcn_s_sleep(8);
+        }
+        if (!ok) __hip_atomic_store(status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        *flag = ok;
+    }
+    __syncthreads();
+    const bool ok = *flag != 0;
+    __syncthreads();
+    return ok;
+}
+
+__device__ __forceinline__ void tile_to_lds(float* t, const f32x16& acc, int li, int h)
+{
+#pragma unroll
+    for (int r = 0; r < 16; ++r) t[((r & 3) + 8 * (r >> 2) + 4 * h) * EPI_LD + li] = acc[r];
+}
+
+// this lane's LDS-DMA source inside a [rows x K] row-major operand: row `row` (already clamped), swizzled 16-B chunk
+__device__ __forceinline__ const float* dma_src(const float* base, long long row, long long ld, int i, int lane)
+{
+    return base + row * ld + 4 * ((lane & 7) ^ ((i >> 1) & 7));
+}
+
+
+}  // namespace ppk_seq

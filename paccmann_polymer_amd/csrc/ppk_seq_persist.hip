@@ -32,30 +32,23 @@
 // bounded: on a timeout the kernel raises a status word and every workgroup leaves.
 #include "ppk_common.h"
 #include "ppk_kernels.h"
+#include "ppk_seq_common.h"
 #include <stdlib.h>
 #include <algorithm>
 
 namespace {
 
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef float f32x16 __attribute__((ext_vector_type(16)));
+using namespace ppk_seq;
 
-constexpr int BK = 32;
 constexpr int MAXT = ppk::SEQP_MAXT, MAXL = ppk::SEQP_MAXL;
 constexpr int STG_BUF = 5 * 1024;              // floats per staging buffer: A slot 0, A slot 1, B r, B z, B n (32 x 32 each)
 constexpr int NBUF = 3;
-constexpr int EPI_LD = 32;                     // floats per transposed row: a thread reads (row = tid / 8, 4 columns), so every
-                                               // 16-lane read group covers 256 contiguous bytes without padding
-constexpr int EPI_TILE = 32 * EPI_LD;
 constexpr int REGION = 4 * 4 * EPI_TILE;       // floats: 4 waves x 4 accumulators, transposed (also staging / stack scratch)
-constexpr int SPIN_LIMIT = 1 << 22;            // polls of ~0.3 us: > 1 s
 constexpr int WL_MAX = 32 * 64;                // floats: this workgroup's slice of the transposed head weights (ldcs <= 64)
 static_assert(NBUF * STG_BUF <= REGION, "staging fits the shared region");
 
-#define PPK_LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
-
 struct SeqArgs {
-    int T, B, H, L, W, D, V, ks, ldcs, ntiles, G, MT, g0, g1, tpx, rb;
+    int T, B, H, L, W, D, V, ks, ldcs, ntiles, G, MT, g0, g1, tpx, xt, rb;
     long long NT;
     const int64_t* tokens;
     const float* table; const float* wx0s;
@@ -68,37 +61,15 @@ struct SeqArgs {
     int bs[MAXT];
 };
 
-template <int N> __device__ __forceinline__ void wait_vmcnt()
-{
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
-}
-__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
-__device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
-__device__ __forceinline__ void st4(float* p, const f32x4& v) { *reinterpret_cast<f32x4*>(p) = v; }
-// Write-through / L1-bypassing 16-byte accesses of hand-off data (cache policy sc1) as raw buffer instructions:
-// base = a wave-uniform pointer, byte_off = this lane's offset (< 2 GiB).  The compiler counts them in vmcnt itself.
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-constexpr int CPOL_SC1 = 16;
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const float* base)
-{
-    return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, 0x7fffffff, 0x00020000);
-}
-__device__ __forceinline__ void st4_sc1(const float* base, long long byte_off, const f32x4& v)
-{
-    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), make_rsrc(base), (int)byte_off, 0, CPOL_SC1);
-}
-__device__ __forceinline__ f32x4 ld4_sc1(const float* base, long long byte_off)
-{
-    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(make_rsrc(base), (int)byte_off, 0, CPOL_SC1));
-}
-
 // LDS of the kernel (file scope so that the non-inlined phases address it with DS instructions, not through flat pointers)
 __shared__ __align__(1024) float g_lds[REGION];      // staging buffers | transposed accumulator partials | stack-phase scratch
 __shared__ __align__(16) float g_wl[WL_MAX];         // rows 32 j .. 32 j + 31 of wcs_t [H, ldcs]: constant for the workgroup
 __shared__ int g_off[MAXT + 1];
 __shared__ int g_flag;
+#ifdef PPK_SEQ_TIMING
 __shared__ long long g_tacc[16];
 __shared__ long long g_tlast;
+#endif
 
 // PPK_SEQ_TIMING build (tools/seq_timing.py): thread 0 adds the shader-clock cycles of every phase into LDS slots
 #ifdef PPK_SEQ_TIMING
@@ -106,35 +77,6 @@ __shared__ long long g_tlast;
 #else
 #define TSTAMP(id) do { } while (0)
 #endif
-
-// ---- group-local synchronisation ----------------------------------------------------------
-// every wave has drained its stores -> barrier -> one counter add
-__device__ __forceinline__ void group_signal(int* ctr)
-{
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (threadIdx.x == 0) __hip_atomic_fetch_add(ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-// one lane polls, acquires, then the workgroup barrier; false = timeout / another workgroup gave up
-__device__ __forceinline__ bool group_wait(int* ctr, int target, int* status, volatile int* flag)
-{
-    if (threadIdx.x == 0) {
-        int ok = 0;
-        for (int it = 0; it < SPIN_LIMIT; ++it) {
-            if (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target) { ok = 1; break; }
-            if ((it & 255) == 255 && __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
-            __builtin_amdgcn_s_sleep(8);
-        }
-        if (!ok) __hip_atomic_store(status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        *flag = ok;
-    }
-    __syncthreads();
-    const bool ok = *flag != 0;
-    __syncthreads();
-    return ok;
-}
 
 // ---- K loop ---------------------------------------------------------------------------------
 // acc[s][q] += A_s[32 x 32 nk] . B_q[32 x 32 nk]^T for the NA active m-tiles s and the gates q = r, z, n (n goes to
@@ -181,18 +123,6 @@ __device__ __forceinline__ void kloop(float* lds, const float* s0, const float* 
             }
         cur = cur == NBUF - 1 ? 0 : cur + 1;
     }
-}
-
-__device__ __forceinline__ void tile_to_lds(float* t, const f32x16& acc, int li, int h)
-{
-#pragma unroll
-    for (int r = 0; r < 16; ++r) t[((r & 3) + 8 * (r >> 2) + 4 * h) * EPI_LD + li] = acc[r];
-}
-
-// this lane's LDS-DMA source inside a [rows x K] row-major operand: row `row` (already clamped), swizzled 16-B chunk
-__device__ __forceinline__ const float* dma_src(const float* base, long long row, long long ld, int i, int lane)
-{
-    return base + row * ld + 4 * ((lane & 7) ^ ((i >> 1) & 7));
 }
 
 // ---- stack heads, distributed: every n-tile workgroup multiplies ITS 32 hidden units of the top layer's new hidden
@@ -539,7 +469,7 @@ __global__ __launch_bounds__(256, 2) void k_seq_fwd(const SeqArgs a)
 {
     float* lds = g_lds;
     int* off = g_off;
-    long long* tacc = g_tacc;
+    long long* tacc = nullptr;
     long long tlast = 0;
 #ifdef PPK_SEQ_TIMING
     if (threadIdx.x == 0) { for (int k = 0; k < 16; ++k) g_tacc[k] = 0; g_tlast = __builtin_readcyclecounter(); }
@@ -551,8 +481,13 @@ __global__ __launch_bounds__(256, 2) void k_seq_fwd(const SeqArgs a)
     // With fewer n-tiles a group's workgroups share an XCD.
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
     int g, j;
-    if (a.tpx > 0) { g = a.g0 + slot / a.tpx; j = xcd * a.tpx + slot % a.tpx; if (j >= a.ntiles) return; }
-    else { g = a.g0 + (slot / a.ntiles) * 8 + xcd; j = slot % a.ntiles; }
+    if (a.tpx > 0) {
+        // XCD x serves tile block x % xt of the groups with g % (8 / xt) == x / xt   (xt = 8: every XCD a tile block of all groups)
+        const int gdiv = 8 / a.xt;
+        g = a.g0 + (slot / a.tpx) * gdiv + xcd / a.xt;
+        j = (xcd % a.xt) * a.tpx + slot % a.tpx;
+        if (j >= a.ntiles) return;
+    } else { g = a.g0 + (slot / a.ntiles) * 8 + xcd; j = slot % a.ntiles; }
     if (g >= a.g1) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     if (tid == 0) {
@@ -671,7 +606,10 @@ int seq_fwd_persist(int64_t T, const int64_t* bs, int64_t B, int64_t NT, int64_t
     SeqArgs a{};
     a.T = (int)T; a.B = (int)B; a.H = (int)H; a.L = (int)L; a.W = (int)W; a.D = (int)D; a.V = (int)V; a.ks = (int)ks; a.ldcs = (int)ldcs;
     a.ntiles = (int)(H / 32);
-    a.tpx = a.ntiles >= 8 ? (a.ntiles + 7) / 8 : 0;          // n-tiles per XCD (0: group-major placement)
+    // XCD placement (speed only): xt tile blocks x 8 / xt group classes; xt = 8: tile-major, 0: group-major (PPK_SEQ_XT)
+    { static int xt_env = -1; if (xt_env < 0) { const char* e = getenv("PPK_SEQ_XT"); xt_env = e ? atoi(e) : 4; }
+      a.xt = a.ntiles >= 8 && (xt_env == 8 || xt_env == 4 || xt_env == 2) ? xt_env : 0; }
+    a.tpx = a.xt > 0 ? (a.ntiles + a.xt - 1) / a.xt : 0;          // n-tiles per XCD (0: group-major placement)
     a.MT = (int)((B + 31) / 32);
     a.G = (a.MT + 1) / 2;
     a.NT = NT;
@@ -707,7 +645,7 @@ int seq_fwd_persist(int64_t T, const int64_t* bs, int64_t B, int64_t NT, int64_t
     }
     int groups_per_launch;
     if (a.tpx > 0) {
-        groups_per_launch = capacity / (8 * a.tpx);                 // grid = 8 tpx workgroups per group (some idle when ntiles % 8 != 0)
+        groups_per_launch = capacity / (a.xt * a.tpx) / (8 / a.xt) * (8 / a.xt);                 // grid = 8 tpx workgroups per group (some idle when ntiles % 8 != 0)
     } else {
         groups_per_launch = capacity / a.ntiles / 8 * 8;
         if (groups_per_launch < 8) groups_per_launch = capacity / a.ntiles;      // fewer than 8 groups at a time: still whole groups
@@ -718,7 +656,7 @@ int seq_fwd_persist(int64_t T, const int64_t* bs, int64_t B, int64_t NT, int64_t
         const int ng = std::min(groups_per_launch, a.G - g0);
         a.g0 = g0;
         a.g1 = g0 + ng;
-        const unsigned grid = a.tpx > 0 ? (unsigned)(8 * a.tpx * ng) : (unsigned)(((ng + 7) / 8) * 8 * a.ntiles);
+        const unsigned grid = a.tpx > 0 ? (unsigned)(8 * a.tpx * ((ng + 8 / a.xt - 1) / (8 / a.xt))) : (unsigned)(((ng + 7) / 8) * 8 * a.ntiles);
         ProfScope prof(PK_SEQ_FWD, flops * (double)ng / (double)a.G, stream);
         k_seq_fwd<<<dim3(grid), dim3(256), 0, stream>>>(a);
         PPK_CHECK_LAUNCH("k_seq_fwd");

@@ -27,6 +27,7 @@
 // table[v] = emb[v] . W_ih0[:, :E]^T + b_ih0 is a [V, 3H] lookup.
 #include "ppk_common.h"
 #include "ppk_kernels.h"
+#include <algorithm>
 #include <vector>
 
 namespace {
@@ -309,10 +310,10 @@ int ppk_stackgru_seq_fwd(int64_t T, const int64_t* batch_sizes_host, int64_t B, 
     return PPK_OK;
 }
 
-size_t ppk_stackgru_seq_bwd_workspace_bytes(int64_t B, int64_t W, int64_t D)
+size_t ppk_stackgru_seq_bwd_workspace_bytes(int64_t B, int64_t H, int64_t L, int64_t W, int64_t D)
 {
-    if (B < 1 || W < 1 || D < 1) return 0;
-    return 2 * ppk_align_up(sizeof(float) * (size_t)B * (size_t)D * (size_t)W, 256);
+    if (B < 1 || H < 1 || L < 1 || W < 1 || D < 1) return 0;
+    return std::max(2 * ppk_align_up(sizeof(float) * (size_t)B * (size_t)D * (size_t)W, 256), ppk::seq_bwd_persist_ws_bytes(B, H, L, W, D));
 }
 
 // dHtop [NT, H]: gradient arriving at the top layer's output of every step
@@ -336,7 +337,11 @@ int ppk_stackgru_seq_bwd(int64_t T, const int64_t* batch_sizes_host, int64_t B, 
     if (rc) return rc;
     if (!w_ih_t || !w_hh_t || !wcs_t || !HP || !gates || !S || !CS || !dHtop || !dXS || !DGI || !DGH || !DCS || !dh0 || !workspace)
         PPK_FAIL(PPK_ERR_NULL, "stackgru_seq_bwd: null pointer");
-    if (ws_bytes < ppk_stackgru_seq_bwd_workspace_bytes(B, W, D)) PPK_FAIL(PPK_ERR_WS, "stackgru_seq_bwd: workspace too small");
+    if (ws_bytes < ppk_stackgru_seq_bwd_workspace_bytes(B, H, L, W, D)) PPK_FAIL(PPK_ERR_WS, "stackgru_seq_bwd: workspace too small");
+    // the whole time loop as one persistent launch (ppk_seq_persist_bwd.hip) when the shape allows it
+    if (ppk::seq_bwd_persist_ok(T, B, NT, H, L, W, D, ks, ldcs))
+        return ppk::seq_bwd_persist(T, batch_sizes_host, B, NT, H, L, W, D, w_ih_t, w_hh_t, wcs_t, HP, gates, S, CS, ldcs,
+                                    dHtop, dXS, ks, DGI, DGH, DCS, dh0, workspace, ws_bytes, stream);
     char* cur = (char*)workspace;
     const size_t sbytes = sizeof(float) * (size_t)B * D * W;
     float* dSa = (float*)ppk_carve(cur, sbytes);

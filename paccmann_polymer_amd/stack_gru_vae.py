@@ -316,7 +316,7 @@ class _StackGRUSeq(torch.autograd.Function):
         DGH = torch.empty(L, NT, 3 * Hp, **f32)
         DCS = torch.empty(NT, ldcs, **f32)
         dh0 = torch.empty(L, B, Hp, **f32)
-        wsb = _lib.ppk_stackgru_seq_bwd_workspace_bytes(B, W, D)
+        wsb = _lib.ppk_stackgru_seq_bwd_workspace_bytes(B, Hp, L, W, D)
         ws = _ws(wsb, dev)
         st = _C.stream()
         _C.check(_lib.ppk_stackgru_seq_bwd(

@@ -17,6 +17,9 @@ names = ['kloop A', 'wait input', 'kloop B', 'heads partial', 'signal', 'wait to
          'stack: loads', 'stack: sync', 'stack: act', 'stack: update', 'stack: sync2', 'epilogue', '-', '-']
 lib = _C.lib
 lib.ppk_dbg_seq_timing_buffer.argtypes = [ctypes.c_void_p]
+lib.ppk_dbg_seq_bwd_timing_buffer.argtypes = [ctypes.c_void_p]
+bnames = ['TOP (wait SB + K = ldcs)', 'gate backward', 'signal + wait E_l', 'P_l K loops', 'dXS partial', 'signal + wait E_0', 'stack backward',
+          'signal SB + P_0 + carry'] + ['-'] * 8
 rng = np.random.default_rng(1234)
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
 seqs, gs, sizes = bench.synth_batch(rng, B // 16, 16)
@@ -26,19 +29,31 @@ model = Encoder(bench.PARAMS, None, None, batch_size=1, batch_mode='Packed')
 G = ((B + 31) // 32 + 1) // 2
 nwg = G * 16
 buf = torch.zeros(nwg * 16, dtype=torch.int64, device='cuda')
-with torch.no_grad():
-    for it in range(3):
-        buf.zero_()
-        lib.ppk_dbg_seq_timing_buffer(ctypes.c_void_p(buf.data_ptr()))
-        torch.cuda.synchronize()
-        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        ev0.record()
-        model.gru_vae.encode(enc)
-        ev1.record()
-        torch.cuda.synchronize()
-        ms = ev0.elapsed_time(ev1)
+bbuf = torch.zeros(nwg * 16, dtype=torch.int64, device='cuda')
+model.gru_vae.train()
+for it in range(3):
+    buf.zero_()
+    bbuf.zero_()
+    lib.ppk_dbg_seq_timing_buffer(ctypes.c_void_p(buf.data_ptr()))
+    lib.ppk_dbg_seq_bwd_timing_buffer(ctypes.c_void_p(bbuf.data_ptr()))
+    torch.cuda.synchronize()
+    ev0, ev1, ev2 = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+    ev0.record()
+    mu, lv = model.gru_vae.encode(enc)
+    ev1.record()
+    (mu.sum() + lv.sum()).backward()
+    ev2.record()
+    torch.cuda.synchronize()
+    ms = ev0.elapsed_time(ev1)
+    msb = ev1.elapsed_time(ev2)
 t = buf.view(nwg, 16).double().cpu().numpy()
 tot = t.sum(1)
 print(f'encode forward {ms:.3f} ms, T = {enc.batch_sizes.numel()}, workgroups {nwg}; cycles per workgroup: mean {tot.mean():.3e} max {tot.max():.3e}')
 for k, n in enumerate(names):
     print(f'  {n:12s} mean {t[:, k].mean():12.0f} ({100 * t[:, k].mean() / tot.mean():5.1f} %)   max {t[:, k].max():12.0f}  min {t[:, k].min():12.0f}')
+t = bbuf.view(nwg, 16).double().cpu().numpy()
+tot = t.sum(1)
+print(f'encode backward (whole autograd pass incl. weight gradients) {msb:.3f} ms; k_seq_bwd cycles per workgroup: mean {tot.mean():.3e} max {tot.max():.3e}')
+for k, n in enumerate(bnames):
+    if n != '-':
+        print(f'  {n:26s} mean {t[:, k].mean():12.0f} ({100 * t[:, k].mean() / tot.mean():5.1f} %)   max {t[:, k].max():12.0f}  min {t[:, k].min():12.0f}')

@@ -98,6 +98,8 @@ __device__ __forceinline__ void kloop(float* lds, const float* s0, const float* 
         __builtin_amdgcn_global_load_lds(s4, PPK_LDS_PTR(base + 4096), 16, 0, 0); s4 += BK;
     };
     __syncthreads();                                  // the shared region is free (previous epilogue / stack phase done)
+    // (refilling a buffer one stage earlier behind a second barrier — three stages in flight — pays in the backward's
+    // leaner stages, ppk_seq_persist_bwd.hip, but measured slower here: 24 MFMAs per stage already cover the latency)
     if (nk > 0) stage(0);
     if (nk > 1) stage(1);
     int cur = 0, nxt = 2;
@@ -332,14 +334,36 @@ __device__ __noinline__ void stack_phase(StackCtx c)
         for (int k = 0; k < RB; ++k) { long long sr; any = any || rowinfo(rho0 + k * c.ntiles, sr); }
         if (!any) continue;                           // workgroup-uniform
         __syncthreads();
-        // heads = partials of the ntiles workgroups added in tile order + bias; ntiles independent 16-byte loads per thread
+        // previous stack rows: the loads of all rows are issued FIRST (up to 16 x 16 bytes in flight per thread), the
+        // partial-head loads right behind them, so both sets share one memory round trip
+        const float* sp[4];
+        bool on[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            long long sr = 0;
+            on[k] = k < RB && rowinfo(rho0 + k * c.ntiles, sr);
+            sp[k] = c.Sprev ? c.Sprev + sr * DW : nullptr;
+        }
+        const int n4 = DW >> 2;
+        const bool vload = c.Sprev && vec;
+        f32x4 tmp[4][4];
+        if (vload) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+#pragma unroll
+                for (int x = 0; x < 4; ++x) {
+                    const int e = x * 256 + tid;
+                    if (on[k] && e < n4) tmp[k][x] = ld4(sp[k] + 4 * e);
+                }
+        }
+        // heads = partials of the ntiles workgroups added in tile order + bias; sixteen independent 16-byte loads per thread
         for (int e = tid; e < RB * (ldcs >> 2); e += 256) {
             const int k = e / (ldcs >> 2), o = (e - k * (ldcs >> 2)) * 4, rho = rho0 + k * c.ntiles;
             long long sr;
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
             if (rowinfo(rho, sr)) {
                 const long long b0 = ((long long)rho * ldcs + o) * 4;
-                for (int j0 = 0; j0 < c.ntiles; j0 += 16) {         // sixteen loads in flight (one memory round trip), added in tile order
+                for (int j0 = 0; j0 < c.ntiles; j0 += 16) {
                     f32x4 p[16];
 #pragma unroll
                     for (int x = 0; x < 16; ++x) {
@@ -354,42 +378,36 @@ __device__ __noinline__ void stack_phase(StackCtx c)
             }
             st4(act + k * ldcs + o, v);
         }
-        // previous stack rows -> LDS: the loads of all rows are issued together (up to 16 x 16 bytes in flight per thread)
-        {
-            const float* sp[4];
-            bool on[4];
+        if (!c.Sprev) {
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                long long sr = 0;
-                on[k] = k < RB && rowinfo(rho0 + k * c.ntiles, sr);
-                sp[k] = c.Sprev ? c.Sprev + sr * DW : nullptr;
-            }
-            if (!c.Sprev) {
+            for (int k = 0; k < 4; ++k) if (on[k]) for (int e = tid; e < DW; e += 256) spl[k * DW4 + e] = 0.f;
+        } else if (vec) {
 #pragma unroll
-                for (int k = 0; k < 4; ++k) if (on[k]) for (int e = tid; e < DW; e += 256) spl[k * DW4 + e] = 0.f;
-            } else if (vec) {
-                const int n4 = DW >> 2;
-                for (int e0 = 0; e0 < n4; e0 += 4 * 256) {
-                    f32x4 tmp[4][4];
+            for (int k = 0; k < 4; ++k)
 #pragma unroll
-                    for (int k = 0; k < 4; ++k)
-#pragma unroll
-                        for (int x = 0; x < 4; ++x) {
-                            const int e = e0 + x * 256 + tid;
-                            if (on[k] && e < n4) tmp[k][x] = ld4(sp[k] + 4 * e);
-                        }
-#pragma unroll
-                    for (int k = 0; k < 4; ++k)
-#pragma unroll
-                        for (int x = 0; x < 4; ++x) {
-                            const int e = e0 + x * 256 + tid;
-                            if (on[k] && e < n4) st4(spl + k * DW4 + 4 * e, tmp[k][x]);
-                        }
+                for (int x = 0; x < 4; ++x) {
+                    const int e = x * 256 + tid;
+                    if (on[k] && e < n4) st4(spl + k * DW4 + 4 * e, tmp[k][x]);
                 }
-            } else {
+            for (int e0 = 4 * 256; e0 < n4; e0 += 4 * 256) {           // rows beyond 4096 floats
 #pragma unroll
-                for (int k = 0; k < 4; ++k) if (on[k]) for (int e = tid; e < DW; e += 256) spl[k * DW4 + e] = sp[k][e];
+                for (int k = 0; k < 4; ++k)
+#pragma unroll
+                    for (int x = 0; x < 4; ++x) {
+                        const int e = e0 + x * 256 + tid;
+                        if (on[k] && e < n4) tmp[k][x] = ld4(sp[k] + 4 * e);
+                    }
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+#pragma unroll
+                    for (int x = 0; x < 4; ++x) {
+                        const int e = e0 + x * 256 + tid;
+                        if (on[k] && e < n4) st4(spl + k * DW4 + 4 * e, tmp[k][x]);
+                    }
             }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) if (on[k]) for (int e = tid; e < DW; e += 256) spl[k * DW4 + e] = sp[k][e];
         }
         TSTAMP(8);
         __syncthreads();

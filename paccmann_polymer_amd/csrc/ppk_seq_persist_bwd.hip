@@ -86,15 +86,16 @@ __device__ __forceinline__ void kloop2(float* lds, const float* x0, const float*
         __builtin_amdgcn_global_load_lds(by, PPK_LDS_PTR(base + 5120), 16, 0, 0); by += adv;
     };
     __syncthreads();                                  // the shared region is free
+    // NBUF stages in flight: a buffer is refilled as soon as every wave holds its fragments of it in registers
     if (nst > 0) stage(0);
     if (nst > 1) stage(1);
-    int cur = 0, nxt = 2;
+    if (nst > 2) stage(2);
+    int cur = 0;
     for (int it = 0; it < nst; ++it) {
-        if (it + 1 < nst) wait_vmcnt<PPW>(); else wait_vmcnt<0>();
+        const int r = nst - 1 - it;
+        if (r >= 2) wait_vmcnt<2 * PPW>(); else if (r == 1) wait_vmcnt<PPW>(); else wait_vmcnt<0>();
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        if (it + 2 < nst) stage(nxt);
-        nxt = nxt == NBUF - 1 ? 0 : nxt + 1;
         const float* base = lds + cur * STG_BUF + xo;
         f32x4 ax[NA], ay[NA], fx, fy;
 #pragma unroll
@@ -104,6 +105,12 @@ __device__ __forceinline__ void kloop2(float* lds, const float* x0, const float*
         }
         fx = *(const f32x4*)(base + 4096);
         fy = *(const f32x4*)(base + 5120);
+        if (it + NBUF < nst) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();             // every wave has read this buffer
+            asm volatile("" ::: "memory");
+            stage(cur);
+        }
 #pragma unroll
         for (int st = 0; st < 4; ++st)
 #pragma unroll
@@ -131,18 +138,24 @@ __device__ __forceinline__ void kloop1(float* lds, const float* x0, const float*
     __syncthreads();
     if (nk > 0) stage(0);
     if (nk > 1) stage(1);
-    int cur = 0, nxt = 2;
+    if (nk > 2) stage(2);
+    int cur = 0;
     for (int it = 0; it < nk; ++it) {
-        if (it + 1 < nk) wait_vmcnt<PPW>(); else wait_vmcnt<0>();
+        const int r = nk - 1 - it;
+        if (r >= 2) wait_vmcnt<2 * PPW>(); else if (r == 1) wait_vmcnt<PPW>(); else wait_vmcnt<0>();
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        if (it + 2 < nk) stage(nxt);
-        nxt = nxt == NBUF - 1 ? 0 : nxt + 1;
         const float* base = lds + cur * STG_BUF + xo;
         f32x4 ax[NA], fx;
 #pragma unroll
         for (int s = 0; s < NA; ++s) ax[s] = *(const f32x4*)(base + s * 1024);
         fx = *(const f32x4*)(base + 4096);
+        if (it + NBUF < nk) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            stage(cur);
+        }
 #pragma unroll
         for (int st = 0; st < 4; ++st)
 #pragma unroll

@@ -48,7 +48,7 @@ constexpr int WL_MAX = 32 * 64;                // floats: this workgroup's slice
 static_assert(NBUF * STG_BUF <= REGION, "staging fits the shared region");
 
 struct SeqArgs {
-    int T, B, H, L, W, D, V, ks, ldcs, ntiles, G, MT, g0, g1, tpx, xt, rb;
+    int T, B, H, L, W, D, V, ks, ldcs, ntiles, G, MT, g0, g1, tpx, xt, rb, pair, hgrid;
     long long NT;
     const int64_t* tokens;
     const float* table; const float* wx0s;
@@ -497,16 +497,29 @@ __global__ __launch_bounds__(256, 2) void k_seq_fwd(const SeqArgs a)
     // matrix, 1.2 MB at H = 512) stays in its 4 MiB L2, instead of every group streaming all 9.8 MB of weights
     // through it each step; the hand-off reads (hidden rows, written through to memory anyway) cross XCDs.
     // With fewer n-tiles a group's workgroups share an XCD.
-    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    // pair mode: the launch's groups sorted by length, first half of the grid = the longer half, second half = the
+    // shorter half mirrored, so that a CU that receives one workgroup of each half (breadth-first dispatch) carries
+    // the same number of row-block steps as every other CU
+    const int half = a.hgrid > 0 && (int)blockIdx.x >= a.hgrid ? 1 : 0;
+    const int bid = (int)blockIdx.x - half * a.hgrid;
+    const int xcd = bid & 7, slot = bid >> 3;
     int g, j;
     if (a.tpx > 0) {
         // XCD x serves tile block x % xt of the groups with g % (8 / xt) == x / xt   (xt = 8: every XCD a tile block of all groups)
         const int gdiv = 8 / a.xt;
-        g = a.g0 + (slot / a.tpx) * gdiv + xcd / a.xt;
+        g = (slot / a.tpx) * gdiv + xcd / a.xt;
         j = (xcd % a.xt) * a.tpx + slot % a.tpx;
         if (j >= a.ntiles) return;
-    } else { g = a.g0 + (slot / a.ntiles) * 8 + xcd; j = slot % a.ntiles; }
-    if (g >= a.g1) return;
+    } else { g = (slot / a.ntiles) * 8 + xcd; j = slot % a.ntiles; }
+    if (a.hgrid > 0) {
+        const int nh = (a.g1 - a.g0 + 1) / 2;
+        if (g >= nh) return;
+        g = half ? a.g1 - 1 - g : a.g0 + g;
+        if (half && g < a.g0 + nh) return;
+    } else {
+        g += a.g0;
+        if (g >= a.g1) return;
+    }
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     if (tid == 0) {
         int s = 0;
@@ -515,8 +528,8 @@ __global__ __launch_bounds__(256, 2) void k_seq_fwd(const SeqArgs a)
     }
     for (int e = tid * 4; e < 32 * a.ldcs; e += 1024) st4(g_wl + e, ld4(a.wcs_t + (long long)32 * j * a.ldcs + e));
     __syncthreads();
-    const int m1 = 2 * a.G - 1 - g;
-    const int r0[2] = {32 * g, m1 < a.MT && m1 != g ? 32 * m1 : -1};
+    const int m0 = a.pair ? 2 * g : g, m1 = a.pair ? 2 * g + 1 : 2 * a.G - 1 - g;
+    const int r0[2] = {32 * m0, m1 < a.MT && m1 != m0 ? 32 * m1 : -1};
     int* ctr = a.ctr + (long long)g * (a.L + 1);
 
     // "step -1": the heads of the initial hidden state of the top layer
@@ -628,6 +641,7 @@ int seq_fwd_persist(int64_t T, const int64_t* bs, int64_t B, int64_t NT, int64_t
     { static int xt_env = -1; if (xt_env < 0) { const char* e = getenv("PPK_SEQ_XT"); xt_env = e ? atoi(e) : 4; }
       a.xt = a.ntiles >= 8 && (xt_env == 8 || xt_env == 4 || xt_env == 2) ? xt_env : 0; }
     a.tpx = a.xt > 0 ? (a.ntiles + a.xt - 1) / a.xt : 0;          // n-tiles per XCD (0: group-major placement)
+    { static int pair_env = -1; if (pair_env < 0) { const char* e = getenv("PPK_SEQ_PAIR"); pair_env = e ? atoi(e) : 0; } a.pair = pair_env; }   // 1: adjacent row blocks per group + mirrored grid halves (measured slower: 18.0 vs 17.3 ms forward; kept for experiments)
     a.MT = (int)((B + 31) / 32);
     a.G = (a.MT + 1) / 2;
     a.NT = NT;
@@ -674,7 +688,10 @@ int seq_fwd_persist(int64_t T, const int64_t* bs, int64_t B, int64_t NT, int64_t
         const int ng = std::min(groups_per_launch, a.G - g0);
         a.g0 = g0;
         a.g1 = g0 + ng;
-        const unsigned grid = a.tpx > 0 ? (unsigned)(8 * a.tpx * ((ng + 8 / a.xt - 1) / (8 / a.xt))) : (unsigned)(((ng + 7) / 8) * 8 * a.ntiles);
+        auto grid_for = [&](int n) { return a.tpx > 0 ? 8 * a.tpx * ((n + 8 / a.xt - 1) / (8 / a.xt)) : ((n + 7) / 8) * 8 * a.ntiles; };
+        a.hgrid = a.pair && ng > 1 ? grid_for((ng + 1) / 2) : 0;
+        if (2 * a.hgrid > capacity) a.hgrid = 0;                  // rounding of the halves: never more workgroups than are resident together
+        const unsigned grid = (unsigned)(a.hgrid > 0 ? 2 * a.hgrid : grid_for(ng));
         ProfScope prof(PK_SEQ_FWD, flops * (double)ng / (double)a.G, stream);
         k_seq_fwd<<<dim3(grid), dim3(256), 0, stream>>>(a);
         PPK_CHECK_LAUNCH("k_seq_fwd");

@@ -51,9 +51,17 @@ tot = t.sum(1)
 print(f'encode forward {ms:.3f} ms, T = {enc.batch_sizes.numel()}, workgroups {nwg}; cycles per workgroup: mean {tot.mean():.3e} max {tot.max():.3e}')
 for k, n in enumerate(names):
     print(f'  {n:12s} mean {t[:, k].mean():12.0f} ({100 * t[:, k].mean() / tot.mean():5.1f} %)   max {t[:, k].max():12.0f}  min {t[:, k].min():12.0f}')
+print('  per group (mean over its workgroups), total / K loops / waits, Mcycles:')
+for g in range(0, G, max(1, G // 8)):
+    r = t[g * 16:(g + 1) * 16]
+    print(f'    group {g:3d}: {r.sum(1).mean() / 1e6:7.2f} / {(r[:, 0] + r[:, 2]).mean() / 1e6:6.2f} / {(r[:, 1] + r[:, 5]).mean() / 1e6:6.2f}')
 t = bbuf.view(nwg, 16).double().cpu().numpy()
 tot = t.sum(1)
 print(f'encode backward (whole autograd pass incl. weight gradients) {msb:.3f} ms; k_seq_bwd cycles per workgroup: mean {tot.mean():.3e} max {tot.max():.3e}')
 for k, n in enumerate(bnames):
     if n != '-':
         print(f'  {n:26s} mean {t[:, k].mean():12.0f} ({100 * t[:, k].mean() / tot.mean():5.1f} %)   max {t[:, k].max():12.0f}  min {t[:, k].min():12.0f}')
+print('  per group (mean over its workgroups), total / K loops / waits, Mcycles:')
+for g in range(0, G, max(1, G // 8)):
+    r = t[g * 16:(g + 1) * 16]
+    print(f'    group {g:3d}: {r.sum(1).mean() / 1e6:7.2f} / {(r[:, 3] + r[:, 7]).mean() / 1e6:6.2f} / {(r[:, 2] + r[:, 5]).mean() / 1e6:6.2f}')

@@ -28,6 +28,7 @@ PARAMS = dict(vocab_size=64, embedding_size=128, rnn_cell_size=512, n_layers=2, 
               latent_dim=256, dropout=0.0, bidirectional=False, use_stack=True, batch_mode='packed',
               padding_index=0, batch_size=1)
 PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+PEAK_BF16_MFMA_TFLOPS = 2500.0     # dense bf16 MFMA (the figure without 2:1 sparsity)
 PEAK_HBM_GBS = 8000.0
 
 
@@ -133,6 +134,8 @@ def main():
     ap.add_argument('--bundles', type=int, default=128)
     ap.add_argument('--bundle-nodes', type=int, default=16)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--dtype', choices=['f32', 'bf16'], default='f32',
+                    help='bf16: the MFMA products of the persistent sequence kernels take bf16 operands (ppk_mfma_mode(1), configs[4] variant)')
     args = ap.parse_args()
 
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
@@ -172,6 +175,8 @@ def main():
     from paccmann_polymer_amd.distributed import GradSync, global_token_count, dp_train_step
     from paccmann_polymer_amd.graph_constrained_loss import graph_loss_segmented
 
+    if P._C.lib.ppk_mfma_mode(1 if args.dtype == 'bf16' else 0) != (1 if args.dtype == 'bf16' else 0):
+        sys.exit('bench.py: ppk_mfma_mode did not take the requested mode')
     torch.manual_seed(0)                                  # identical weights on every rank
     model = Encoder(PARAMS, None, None, batch_size=1, batch_mode='Packed')
     model.gru_vae.train()
@@ -231,7 +236,8 @@ def main():
     top = kinds[0]
     is_gemm = top['kernel'].startswith(('k_gemm', 'k_nt', 'k_tn', 'k_seq'))        # fp32-MFMA GEMM families: work = FLOPs
     achieved = top['work'] / (top['ms'] * 1e-3) / (1e12 if is_gemm else 1e9)
-    peak = PEAK_FP32_MFMA_TFLOPS if is_gemm else PEAK_HBM_GBS
+    seq_bf16 = args.dtype == 'bf16' and top['kernel'].startswith('k_seq')
+    peak = (PEAK_BF16_MFMA_TFLOPS if seq_bf16 else PEAK_FP32_MFMA_TFLOPS) if is_gemm else PEAK_HBM_GBS
     roofline = dict(bound='mfma' if is_gemm else 'hbm', achieved=round(achieved, 2), peak=peak,
                     unit='TFLOP/s' if is_gemm else 'GB/s', frac=round(achieved / peak, 4), traffic=None,
                     kernel=top['kernel'], launches_per_step=top['launches'],
@@ -244,10 +250,10 @@ def main():
     out = dict(metric='training samples/sec (whole node)', value=round(B * world / (dt / args.steps), 1),
                unit='samples/s', n_gpus=world, steps=args.steps, warmup=args.warmup,
                ms_per_step=round(ms_per_step, 3), higher_is_better=True, scaling='weak', vs_baseline=None,
-               dtype='f32', data='synthetic',
+               dtype=args.dtype, data='synthetic',
                config=dict(workload=f'configs[1]: graph-regularised SMILES-VAE step, batch {B}/GPU = {args.bundles} bundles x '
                                     f'{args.bundle_nodes} SMILES (len 20..100), StackGRU VAE V64 E128 H512 L2 stack50x50 Z256, '
-                                    f'graph_gamma 1, Adam lr 1e-4, fp32', global_batch=B * world,
+                                    f'graph_gamma 1, Adam lr 1e-4, ' + ('fp32' if args.dtype == 'f32' else 'bf16 operands / fp32 accumulation in the sequence-kernel MFMA products, fp32 elsewhere (configs[4] variant)'), global_batch=B * world,
                            tokens_per_gpu=n_tokens, parallelism=f'dp{world}'),
                roofline=roofline, final_loss=float(loss))
     if rehearsal:

@@ -12,8 +12,12 @@
  *  - plain pointers and sizes only; all pointers are DEVICE pointers unless
  *    the parameter is documented as host;
  *  - the caller allocates every buffer including the workspace
- *    (ppk_*_workspace_bytes); the library never allocates device memory,
- *    keeps no global state and never synchronises the stream;
+ *    (ppk_*_workspace_bytes); the library never allocates device memory and
+ *    never synchronises the stream.  Its only process-wide state: the opt-in
+ *    timing table (ppk_prof_*), the dispatch knobs ppk_nt_small_grid_limit /
+ *    ppk_seq_persist_mode / ppk_mfma_mode (and the PPK_* environment variables
+ *    read once behind them), the cached device properties, and the per-device
+ *    address of the static array behind ppk_colsum_noalloc;
  *  - every call enqueues on `stream` (a hipStream_t passed as void*);
  *  - return value: 0 on success, a negative PPK_ERR_* otherwise, with a
  *    message available from ppk_last_error() (thread-local);
@@ -155,6 +159,16 @@ int64_t ppk_nt_small_grid_limit(int64_t limit);
  * (one launch per layer-step, the round-1 schedule), -1 / 1 switch it back on, any other value only queries.
  * Process-global like ppk_nt_small_grid_limit.  Returns the value in force. */
 int ppk_seq_persist_mode(int mode);
+
+/* Arithmetic of the MFMA products of K1's persistent sequence kernels (BASELINE.json configs[4], "bf16-MFMA variant
+ * with stated tolerance"; no reference counterpart — the reference computes in fp32 throughout).
+ *   0 (default): fp32 operands, v_mfma_f32_32x32x2_f32 — the parity path (results match the fp64 oracle to 1e-5).
+ *   1: operands rounded to bf16 (round to nearest even) in registers, v_mfma_f32_32x32x8_bf16, fp32 accumulation;
+ *      everything outside the products (gate math, stack, hand-offs, memory) stays fp32.  Tolerance vs mode 0 on the
+ *      training step: loss 2e-3 relative, gradients 5e-2 of the largest entry per tensor (tests/test_gpu_bf16.py).
+ * Takes effect only where the persistent kernels run (ppk_seq_persist_mode != 0 and a supported shape).  Any other
+ * value only queries.  Process-global.  Returns the value in force. */
+int ppk_mfma_mode(int mode);
 
 /* ---- K1: stack-augmented GRU sequence (packed, length-sorted batch) -------
  * Replaces the per-timestep loop of paccmann_chemistry StackGRU / nn.GRU that

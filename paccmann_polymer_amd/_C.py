@@ -44,6 +44,7 @@ SIGNATURES = {
                              ptr, c_i64, ptr, ptr, c_sz, ptr]),
     'ppk_gemm_tn_colsum_f32': (c_int, [c_i64, c_i64, c_i64, ptr, c_i64, ptr, c_i64, ptr, c_i64, ptr, ptr, c_sz, ptr]),
     'ppk_nt_small_grid_limit': (c_i64, [c_i64]),
+    'ppk_mfma_mode': (c_int, [c_int]),
     'ppk_seq_persist_mode': (c_int, [c_int]),
     'ppk_hop_distances': (c_int, [ptr, ptr, ptr, ptr, ptr, c_i64, c_i64, c_int, ptr, ptr, ptr, ptr]),
     'ppk_stackgru_seq_fwd_workspace_bytes': (c_sz, [c_i64, c_i64, c_i64, c_i64]),

@@ -41,6 +41,7 @@ int gemm_ntF(const NtProblem* ps, int count, hipStream_t stream);    // 128 x (3
 // ---- persistent StackGRU sequence kernels (ppk_seq_persist.hip): the whole time loop in one launch,
 //      row-block groups synchronised only among their own workgroups ----
 constexpr int SEQP_MAXT = 512, SEQP_MAXL = 8;
+int mfma_mode(int mode = -1);        // 0 fp32 operands (default), 1 bf16 operands; other values only query
 int seq_persist_mode(int mode);      // -1 auto (default), 0 never, 1 whenever supported; other values only query
 bool seq_fwd_persist_ok(int64_t T, int64_t B, int64_t NT, int64_t H, int64_t L, int64_t W, int64_t D, int64_t ks, int64_t ldcs);
 size_t seq_fwd_persist_ws_bytes(int64_t B, int64_t H, int64_t L, int64_t W);

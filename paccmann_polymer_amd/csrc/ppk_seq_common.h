@@ -87,4 +87,37 @@ __device__ __forceinline__ const float* dma_src(const float* base, long long row
 }
 
 
+
+// ---- MFMA over this lane's four K values of a chunk (fragment f32x4 = 4 consecutive k of one row) ----------------
+// fp32: four v_mfma_f32_32x32x2_f32.  BF (the bf16-operand variant, ppk_mfma_mode(1)): operands rounded to bf16
+// (round to nearest even, v_cvt_pk_bf16_f32) in registers, ONE v_mfma_f32_32x32x8_bf16, fp32 accumulation; memory
+// stays fp32.
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2_ __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2_ __attribute__((ext_vector_type(2)));
+typedef unsigned u32x2_ __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ s16x4 to_bf16x4(const f32x4& x)
+{
+    const bf16x2_ lo = __builtin_convertvector(f32x2_{x[0], x[1]}, bf16x2_), hi = __builtin_convertvector(f32x2_{x[2], x[3]}, bf16x2_);
+    const u32x2_ r = {__builtin_bit_cast(unsigned, lo), __builtin_bit_cast(unsigned, hi)};
+    return __builtin_bit_cast(s16x4, r);
+}
+template <bool BF> struct Frag;
+template <> struct Frag<false> {
+    f32x4 v;
+    __device__ __forceinline__ void set(const f32x4& x) { v = x; }
+};
+template <> struct Frag<true> {
+    s16x4 v;
+    __device__ __forceinline__ void set(const f32x4& x) { v = to_bf16x4(x); }
+};
+__device__ __forceinline__ void mma_chunk(f32x16& acc, const Frag<false>& a, const Frag<false>& b, int st)
+{
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.v[st], b.v[st], acc, 0, 0, 0);
+}
+__device__ __forceinline__ void mma_chunk(f32x16& acc, const Frag<true>& a, const Frag<true>& b, int st)
+{
+    if (st == 0) acc = __builtin_amdgcn_mfma_f32_32x32x8bf16_1k(a.v, b.v, acc, 0, 0, 0);
+}
+
 }  // namespace ppk_seq

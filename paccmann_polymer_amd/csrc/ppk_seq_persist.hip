@@ -82,7 +82,7 @@ __shared__ long long g_tlast;
 // acc[s][q] += A_s[32 x 32 nk] . B_q[32 x 32 nk]^T for the NA active m-tiles s and the gates q = r, z, n (n goes to
 // accumulator NSEL: 2 = input side, 3 = hidden side); the wave takes chunk `wave` of every K tile.
 // src[0..1]: this lane's source of its LDS-DMA piece of A slot 0 / 1, src[2..4]: of B gate r / z / n.
-template <int NA, int NSEL>
+template <int NA, int NSEL, bool BF>
 __device__ __forceinline__ void kloop(float* lds, const float* s0, const float* s1, const float* s2, const float* s3, const float* s4,
                                       int nk, f32x16 (&acc)[2][4], int wave, int lane)
 {
@@ -110,18 +110,18 @@ __device__ __forceinline__ void kloop(float* lds, const float* s0, const float* 
         if (it + 2 < nk) stage(nxt);
         nxt = nxt == NBUF - 1 ? 0 : nxt + 1;
         const float* base = lds + cur * STG_BUF + xo;
-        f32x4 a[NA], b[3];
+        Frag<BF> a[NA], b[3];
 #pragma unroll
-        for (int s = 0; s < NA; ++s) a[s] = *(const f32x4*)(base + s * 1024);
+        for (int s = 0; s < NA; ++s) a[s].set(*(const f32x4*)(base + s * 1024));
 #pragma unroll
-        for (int q = 0; q < 3; ++q) b[q] = *(const f32x4*)(base + (2 + q) * 1024);
+        for (int q = 0; q < 3; ++q) b[q].set(*(const f32x4*)(base + (2 + q) * 1024));
 #pragma unroll
         for (int st = 0; st < 4; ++st)
 #pragma unroll
             for (int s = 0; s < NA; ++s) {
-                acc[s][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s][st], b[0][st], acc[s][0], 0, 0, 0);
-                acc[s][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s][st], b[1][st], acc[s][1], 0, 0, 0);
-                acc[s][NSEL] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s][st], b[2][st], acc[s][NSEL], 0, 0, 0);
+                mma_chunk(acc[s][0], a[s], b[0], st);
+                mma_chunk(acc[s][1], a[s], b[1], st);
+                mma_chunk(acc[s][NSEL], a[s], b[2], st);
             }
         cur = cur == NBUF - 1 ? 0 : cur + 1;
     }
@@ -180,7 +180,7 @@ __device__ __forceinline__ HeadsCtx heads_ctx(const SeqArgs& a, int g, int j, in
 struct Step { int n[2]; long long base[2], pbase[2]; };   // active rows, packed row of the slot's first row now / one step earlier
 
 // ---- one GRU layer of one step ------------------------------------------------------------------
-template <int NA>
+template <int NA, bool BF>
 __device__ __forceinline__ bool cell(const SeqArgs& a, float* lds, volatile int* flag, const int* r0, const Step& st, int t, int l,
                                      int g, int j, int wave, int lane, long long* tacc, long long& tlast)
 {
@@ -219,7 +219,7 @@ __device__ __forceinline__ bool cell(const SeqArgs& a, float* lds, volatile int*
         }
         const float* w = a.w_hh[l];
         const int u = 32 * j + i;
-        kloop<NA, 3>(lds, sa[0], sa[1], dma_src(w, u, H, i, lane), dma_src(w, (long long)H + u, H, i, lane),
+        kloop<NA, 3, BF>(lds, sa[0], sa[1], dma_src(w, u, H, i, lane), dma_src(w, (long long)H + u, H, i, lane),
                      dma_src(w, 2LL * H + u, H, i, lane), H / BK, acc, wave, lane);
     }
     TSTAMP(0);
@@ -240,7 +240,7 @@ __device__ __forceinline__ bool cell(const SeqArgs& a, float* lds, volatile int*
         }
         const float* w = l == 0 ? a.wx0s : a.w_ih[l];
         const int u = 32 * j + i;
-        kloop<NA, 2>(lds, sa[0], sa[1], dma_src(w, u, K, i, lane), dma_src(w, (long long)H + u, K, i, lane),
+        kloop<NA, 2, BF>(lds, sa[0], sa[1], dma_src(w, u, K, i, lane), dma_src(w, (long long)H + u, K, i, lane),
                      dma_src(w, 2LL * H + u, K, i, lane), K / BK, acc, wave, lane);
     }
     TSTAMP(2);
@@ -483,6 +483,7 @@ __device__ __forceinline__ StackCtx stack_ctx(const SeqArgs& a, const int* r0, c
     c.r0a = r0[0]; c.r0b = r0[1];
     return c;
 }
+template <bool BF>
 __global__ __launch_bounds__(256, 2) void k_seq_fwd(const SeqArgs a)
 {
     float* lds = g_lds;
@@ -561,8 +562,8 @@ __global__ __launch_bounds__(256, 2) void k_seq_fwd(const SeqArgs a)
             st.pbase[s] = (long long)(t > 0 ? off[t - 1] : 0) + (r0[s] >= 0 ? r0[s] : 0);
         }
         for (int l = 0; l < a.L; ++l) {
-            const bool ok = st.n[1] > 0 ? cell<2>(a, lds, &g_flag, r0, st, t, l, g, j, wave, lane, tacc, tlast)
-                                        : cell<1>(a, lds, &g_flag, r0, st, t, l, g, j, wave, lane, tacc, tlast);
+            const bool ok = st.n[1] > 0 ? cell<2, BF>(a, lds, &g_flag, r0, st, t, l, g, j, wave, lane, tacc, tlast)
+                                        : cell<1, BF>(a, lds, &g_flag, r0, st, t, l, g, j, wave, lane, tacc, tlast);
             if (!ok) return;
         }
         if (t + 1 < a.T && a.bs[t + 1] > r0[0]) {
@@ -600,6 +601,14 @@ int force_mode()
 }  // namespace
 
 namespace ppk {
+
+int mfma_mode(int mode)
+{
+    static int g_mfma = -1;
+    if (g_mfma < 0) { const char* e = getenv("PPK_MFMA"); g_mfma = e && atoi(e) == 1 ? 1 : 0; }
+    if (mode == 0 || mode == 1) g_mfma = mode;
+    return g_mfma;
+}
 
 int seq_persist_mode(int mode)
 {
@@ -672,7 +681,7 @@ int seq_fwd_persist(int64_t T, const int64_t* bs, int64_t B, int64_t NT, int64_t
         int dev = 0, cus = 0, per = 0;
         PPK_HIP(hipGetDevice(&dev));
         PPK_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-        PPK_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, k_seq_fwd, 256, 0));
+        PPK_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, k_seq_fwd<false>, 256, 0));
         capacity = std::max(1, per) * std::max(1, cus);
     }
     int groups_per_launch;
@@ -693,7 +702,8 @@ int seq_fwd_persist(int64_t T, const int64_t* bs, int64_t B, int64_t NT, int64_t
         if (2 * a.hgrid > capacity) a.hgrid = 0;                  // rounding of the halves: never more workgroups than are resident together
         const unsigned grid = (unsigned)(a.hgrid > 0 ? 2 * a.hgrid : grid_for(ng));
         ProfScope prof(PK_SEQ_FWD, flops * (double)ng / (double)a.G, stream);
-        k_seq_fwd<<<dim3(grid), dim3(256), 0, stream>>>(a);
+        if (ppk::mfma_mode() == 1) k_seq_fwd<true><<<dim3(grid), dim3(256), 0, stream>>>(a);
+        else k_seq_fwd<false><<<dim3(grid), dim3(256), 0, stream>>>(a);
         PPK_CHECK_LAUNCH("k_seq_fwd");
     }
     return PPK_OK;

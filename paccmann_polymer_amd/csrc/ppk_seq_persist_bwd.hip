@@ -66,7 +66,7 @@ __shared__ long long g_tlast;
 //   accX[s] += Ax_s . Bx^T     accY[s] += Ay_s . By^T
 // SHARE: Ay == Ax (staged once: the dr, dz columns, where dgi == dgh).  accX and accY may be the SAME accumulators
 // (two consecutive K tiles of one product: the caller passes sources 32 columns apart and advances by 64).
-template <int NA, bool SHARE>
+template <int NA, bool SHARE, bool BF>
 __device__ __forceinline__ void kloop2(float* lds, const float* x0, const float* x1, const float* y0, const float* y1,
                                        const float* bx, const float* by, int adv, int nst,
                                        f32x16 (&accX)[2], f32x16 (&accY)[2], int wave, int lane)
@@ -97,14 +97,14 @@ __device__ __forceinline__ void kloop2(float* lds, const float* x0, const float*
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         const float* base = lds + cur * STG_BUF + xo;
-        f32x4 ax[NA], ay[NA], fx, fy;
+        Frag<BF> ax[NA], ay[NA], fx, fy;
 #pragma unroll
         for (int s = 0; s < NA; ++s) {
-            ax[s] = *(const f32x4*)(base + s * 1024);
-            if constexpr (!SHARE) ay[s] = *(const f32x4*)(base + 2048 + s * 1024); else ay[s] = ax[s];
+            ax[s].set(*(const f32x4*)(base + s * 1024));
+            if constexpr (!SHARE) ay[s].set(*(const f32x4*)(base + 2048 + s * 1024)); else ay[s] = ax[s];
         }
-        fx = *(const f32x4*)(base + 4096);
-        fy = *(const f32x4*)(base + 5120);
+        fx.set(*(const f32x4*)(base + 4096));
+        fy.set(*(const f32x4*)(base + 5120));
         if (it + NBUF < nst) {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();             // every wave has read this buffer
@@ -115,15 +115,15 @@ __device__ __forceinline__ void kloop2(float* lds, const float* x0, const float*
         for (int st = 0; st < 4; ++st)
 #pragma unroll
             for (int s = 0; s < NA; ++s) {
-                accX[s] = __builtin_amdgcn_mfma_f32_32x32x2f32(ax[s][st], fx[st], accX[s], 0, 0, 0);
-                accY[s] = __builtin_amdgcn_mfma_f32_32x32x2f32(ay[s][st], fy[st], accY[s], 0, 0, 0);
+                mma_chunk(accX[s], ax[s], fx, st);
+                mma_chunk(accY[s], ay[s], fy, st);
             }
         cur = cur == NBUF - 1 ? 0 : cur + 1;
     }
 }
 
 // one product, one K tile per stage (odd remainders and K = 32 products)
-template <int NA>
+template <int NA, bool BF>
 __device__ __forceinline__ void kloop1(float* lds, const float* x0, const float* x1, const float* bx, int nk, f32x16 (&acc)[2], int wave, int lane)
 {
     constexpr int PPW = 1 + NA;
@@ -146,10 +146,10 @@ __device__ __forceinline__ void kloop1(float* lds, const float* x0, const float*
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         const float* base = lds + cur * STG_BUF + xo;
-        f32x4 ax[NA], fx;
+        Frag<BF> ax[NA], fx;
 #pragma unroll
-        for (int s = 0; s < NA; ++s) ax[s] = *(const f32x4*)(base + s * 1024);
-        fx = *(const f32x4*)(base + 4096);
+        for (int s = 0; s < NA; ++s) ax[s].set(*(const f32x4*)(base + s * 1024));
+        fx.set(*(const f32x4*)(base + 4096));
         if (it + NBUF < nk) {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
@@ -159,19 +159,19 @@ __device__ __forceinline__ void kloop1(float* lds, const float* x0, const float*
 #pragma unroll
         for (int st = 0; st < 4; ++st)
 #pragma unroll
-            for (int s = 0; s < NA; ++s) acc[s] = __builtin_amdgcn_mfma_f32_32x32x2f32(ax[s][st], fx[st], acc[s], 0, 0, 0);
+            for (int s = 0; s < NA; ++s) mma_chunk(acc[s], ax[s], fx, st);
         cur = cur == NBUF - 1 ? 0 : cur + 1;
     }
 }
 
 // acc[s] += A_s[.. x 32 nk] . B[.. x 32 nk]^T, two K tiles per stage (+ one single stage when nk is odd)
-template <int NA>
+template <int NA, bool BF>
 __device__ __forceinline__ void kloop_one_product(float* lds, const float* x0, const float* x1, const float* bx, int nk,
                                                   f32x16 (&acc)[2], int wave, int lane)
 {
     const int n2 = nk >> 1;
-    if (n2 > 0) kloop2<NA, false>(lds, x0, x1, x0 + BK, x1 + BK, bx, bx + BK, 2 * BK, n2, acc, acc, wave, lane);
-    if (nk & 1) kloop1<NA>(lds, x0 + 2 * BK * n2, x1 + 2 * BK * n2, bx + 2 * BK * n2, 1, acc, wave, lane);
+    if (n2 > 0) kloop2<NA, false, BF>(lds, x0, x1, x0 + BK, x1 + BK, bx, bx + BK, 2 * BK, n2, acc, acc, wave, lane);
+    if (nk & 1) kloop1<NA, BF>(lds, x0 + 2 * BK * n2, x1 + 2 * BK * n2, bx + 2 * BK * n2, 1, acc, wave, lane);
 }
 
 struct Step {
@@ -475,7 +475,7 @@ __device__ __forceinline__ const float* a_src(const float* base, long long row0,
     return dma_src(base, row0 + ic, ld, i, lane);
 }
 
-template <int NA>
+template <int NA, bool BF>
 __device__ __forceinline__ bool step_bwd(const BwdArgs& a, float* lds, const int* r0, const int* off, const Step& st, int t, int k,
                                          int g, int j, int wave, int lane)
 {
@@ -495,8 +495,8 @@ __device__ __forceinline__ bool step_bwd(const BwdArgs& a, float* lds, const int
         const float* s0 = a_src(a.DCS, st.nbase[0], st.nn[0], a.ldcs, i, lane);
         const float* s1 = a_src(a.DCS, st.nbase[1], NA == 2 ? st.nn[1] : 0, a.ldcs, i, lane);
         const float* sx = dma_src(a.wcs_t, ub, a.ldcs, i, lane);
-        if (NA == 2 && st.nn[1] > 0) kloop_one_product<2>(lds, s0, s1, sx, a.ldcs / BK, accD, wave, lane);
-        else kloop_one_product<1>(lds, s0, s0, sx, a.ldcs / BK, accD, wave, lane);
+        if (NA == 2 && st.nn[1] > 0) kloop_one_product<2, BF>(lds, s0, s1, sx, a.ldcs / BK, accD, wave, lane);
+        else kloop_one_product<1, BF>(lds, s0, s0, sx, a.ldcs / BK, accD, wave, lane);
     }
     TSTAMP(0);
     for (int l = L - 1; l >= 0; --l) {
@@ -539,10 +539,10 @@ __device__ __forceinline__ bool step_bwd(const BwdArgs& a, float* lds, const int
             const float* s1 = a_src(gi, st.base[1], NA == 2 ? st.n[1] : 0, H3, i, lane);
             const float* sx = dma_src(wi, ub, H3, i, lane);
             const float* sy = dma_src(wh, ub, H3, i, lane);
-            kloop2<NA, true>(lds, s0, s1, s0, s1, sx, sy, BK, 2 * H / BK, accD, accC, wave, lane);        // dr, dz: dgi == dgh, staged once
+            kloop2<NA, true, BF>(lds, s0, s1, s0, s1, sx, sy, BK, 2 * H / BK, accD, accC, wave, lane);        // dr, dz: dgi == dgh, staged once
             const float* t0 = a_src(gh, st.base[0], st.n[0], H3, i, lane);
             const float* t1 = a_src(gh, st.base[1], NA == 2 ? st.n[1] : 0, H3, i, lane);
-            kloop2<NA, false>(lds, s0 + 2 * H, s1 + 2 * H, t0 + 2 * H, t1 + 2 * H, sx + 2 * H, sy + 2 * H, BK, H / BK,
+            kloop2<NA, false, BF>(lds, s0 + 2 * H, s1 + 2 * H, t0 + 2 * H, t1 + 2 * H, sx + 2 * H, sy + 2 * H, BK, H / BK,
                               accD, accC, wave, lane);                                                    // dn with W_ih, dn r with W_hh
         }
         TSTAMP(3);
@@ -575,7 +575,7 @@ __device__ __forceinline__ bool step_bwd(const BwdArgs& a, float* lds, const int
         const float* s0 = a_src(gh, st.base[0], st.n[0], H3, i, lane);
         const float* s1 = a_src(gh, st.base[1], NA == 2 ? st.n[1] : 0, H3, i, lane);
         const float* sy = dma_src(a.w_hh_t[0], ub, H3, i, lane);
-        kloop_one_product<NA>(lds, s0, s1, sy, H3 / BK, accC, wave, lane);
+        kloop_one_product<NA, BF>(lds, s0, s1, sy, H3 / BK, accC, wave, lane);
 #pragma unroll
         for (int s = 0; s < NA; ++s) {
             __syncthreads();
@@ -591,6 +591,7 @@ __device__ __forceinline__ bool step_bwd(const BwdArgs& a, float* lds, const int
     return true;
 }
 
+template <bool BF>
 __global__ __launch_bounds__(256, 2) void k_seq_bwd(const BwdArgs a)
 {
     float* lds = g_lds;
@@ -642,8 +643,8 @@ __global__ __launch_bounds__(256, 2) void k_seq_bwd(const BwdArgs a)
             st.base[s] = (long long)off[t] + (r0[s] >= 0 ? r0[s] : 0);
             st.nbase[s] = (long long)(t + 1 < a.T ? off[t + 1] : 0) + (r0[s] >= 0 ? r0[s] : 0);
         }
-        const bool ok = st.n[1] > 0 ? step_bwd<2>(a, lds, r0, off, st, t, k, g, j, wave, lane)
-                                    : step_bwd<1>(a, lds, r0, off, st, t, k, g, j, wave, lane);
+        const bool ok = st.n[1] > 0 ? step_bwd<2, BF>(a, lds, r0, off, st, t, k, g, j, wave, lane)
+                                    : step_bwd<1, BF>(a, lds, r0, off, st, t, k, g, j, wave, lane);
         if (!ok) return;
     }
     // the stack of step 0 read the INITIAL hidden state of the top layer: dh0[L-1] += DCS_0 . [W_c ; W_s]
@@ -657,8 +658,8 @@ __global__ __launch_bounds__(256, 2) void k_seq_bwd(const BwdArgs a)
         const float* s0 = a_src(a.DCS, r0[0], n0, a.ldcs, i, lane);
         const float* s1 = a_src(a.DCS, r0[1] >= 0 ? r0[1] : 0, n1, a.ldcs, i, lane);
         const float* sx = dma_src(a.wcs_t, 32 * j + i, a.ldcs, i, lane);
-        if (n1 > 0) kloop_one_product<2>(lds, s0, s1, sx, a.ldcs / BK, accD, wave, lane);
-        else kloop_one_product<1>(lds, s0, s0, sx, a.ldcs / BK, accD, wave, lane);
+        if (n1 > 0) kloop_one_product<2, BF>(lds, s0, s1, sx, a.ldcs / BK, accD, wave, lane);
+        else kloop_one_product<1, BF>(lds, s0, s0, sx, a.ldcs / BK, accD, wave, lane);
         for (int s = 0; s < 2; ++s) {
             const int n = s ? n1 : n0;
             if (n == 0) continue;
@@ -760,7 +761,7 @@ int seq_bwd_persist(int64_t T, const int64_t* bs, int64_t B, int64_t NT, int64_t
         int dev = 0, cus = 0, per = 0;
         PPK_HIP(hipGetDevice(&dev));
         PPK_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-        PPK_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, k_seq_bwd, 256, 0));
+        PPK_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, k_seq_bwd<false>, 256, 0));
         capacity = std::max(1, per) * std::max(1, cus);
     }
     int groups_per_launch;
@@ -781,7 +782,8 @@ int seq_bwd_persist(int64_t T, const int64_t* bs, int64_t B, int64_t NT, int64_t
         if (2 * a.hgrid > capacity) a.hgrid = 0;                  // rounding of the halves: never more workgroups than are resident together
         const unsigned grid = (unsigned)(a.hgrid > 0 ? 2 * a.hgrid : grid_for(ng));
         ProfScope prof(PK_SEQ_BWD, flops * (double)ng / (double)a.G, stream);
-        k_seq_bwd<<<dim3(grid), dim3(256), 0, stream>>>(a);
+        if (ppk::mfma_mode() == 1) k_seq_bwd<true><<<dim3(grid), dim3(256), 0, stream>>>(a);
+        else k_seq_bwd<false><<<dim3(grid), dim3(256), 0, stream>>>(a);
         PPK_CHECK_LAUNCH("k_seq_bwd");
     }
     return PPK_OK;

@@ -397,5 +397,6 @@ int ppk_stackgru_seq_bwd(int64_t T, const int64_t* batch_sizes_host, int64_t B, 
 // Test / tuning hook: -1 = the persistent sequence kernels run whenever the shape allows (default), 0 = never
 // (per-timestep launches), 1 = same as -1; any other value only queries.  Returns the value in force.
 int ppk_seq_persist_mode(int mode) { return ppk::seq_persist_mode(mode); }
+int ppk_mfma_mode(int mode) { return ppk::mfma_mode(mode); }
 
 }  // extern "C"

@@ -164,9 +164,10 @@ int ppk_seq_persist_mode(int mode);
  * with stated tolerance"; no reference counterpart — the reference computes in fp32 throughout).
  *   0 (default): fp32 operands, v_mfma_f32_32x32x2_f32 — the parity path (results match the fp64 oracle to 1e-5).
  *   1: operands rounded to bf16 (round to nearest even) in registers, v_mfma_f32_32x32x8_bf16, fp32 accumulation;
- *      everything outside the products (gate math, stack, hand-offs, memory) stays fp32.  Tolerance vs mode 0 on the
+ *      everything outside the products (gate math, stack, hand-offs, memory) stays fp32.  The long-K weight-gradient
+ *      GEMM behind ppk_gemm_tn_colsum_f32 / ppk_gemm_f32 (TN, k_tn128) follows the same mode.  Tolerance vs mode 0 on the
  *      training step: loss 2e-3 relative, gradients 5e-2 of the largest entry per tensor (tests/test_gpu_bf16.py).
- * Takes effect only where the persistent kernels run (ppk_seq_persist_mode != 0 and a supported shape).  Any other
+ * In K1 it takes effect only where the persistent kernels run (ppk_seq_persist_mode != 0 and a supported shape).  Any other
  * value only queries.  Process-global.  Returns the value in force. */
 int ppk_mfma_mode(int mode);
 

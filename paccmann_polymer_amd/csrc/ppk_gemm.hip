@@ -18,6 +18,7 @@
 // sums in slice order (bitwise reproducible, no atomics).
 #include "ppk_common.h"
 #include "ppk_kernels.h"
+#include "ppk_seq_common.h"
 #include <stdlib.h>
 
 namespace {
@@ -259,6 +260,7 @@ __global__ __launch_bounds__(256) void k_gemm(const GemmBatch gb)
 #define PPK_LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
 constexpr int TN_BUF = 2 * BK * 128;           // floats per stage (A image + B image)
 
+template <bool BF>
 __global__ __launch_bounds__(256) void k_tn128(const GemmArgs g)
 {
     __shared__ __align__(1024) float lds[2 * TN_BUF];
@@ -295,6 +297,16 @@ __global__ __launch_bounds__(256) void k_tn128(const GemmArgs g)
         offb[i] = BK * 128 + h * 128 + 4 * ((mb >> 2) ^ (8 * h)) + (mb & 3);
     }
 
+    int swa[2][2], swb[2][2];                       // bf16 variant: in-row offsets of (m, parity of k)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int pz = 0; pz < 2; ++pz) {
+            const int ma = wm * 64 + i * 32 + li, mb = wn * 64 + i * 32 + li;
+            swa[i][pz] = 4 * ((ma >> 2) ^ (8 * pz)) + (ma & 3);
+            swb[i][pz] = 4 * ((mb >> 2) ^ (8 * pz)) + (mb & 3);
+        }
+
     f32x16 acc[2][2];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -315,6 +327,30 @@ __global__ __launch_bounds__(256) void k_tn128(const GemmArgs g)
         __builtin_amdgcn_s_barrier();
         if (it + 1 < nk) stage(cur ^ 1);
         const float* base = lds + cur * TN_BUF;
+        if constexpr (BF) {
+            // bf16-operand variant (ppk_mfma_mode(1)): lane (m, h) takes k = 8 c + 4 h + 0..3 of every 8-row chunk,
+            // rounds to bf16 in registers (round to nearest even), one v_mfma_f32_32x32x8_bf16 per chunk and tile pair
+#pragma unroll
+            for (int c = 0; c < BK / 8; ++c) {
+                ppk_seq::s16x4 af[2], bf[2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    f32x4 av, bv;
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        av[t] = base[(8 * c + 4 * h + t) * 128 + swa[i][t & 1]];
+                        bv[t] = base[BK * 128 + (8 * c + 4 * h + t) * 128 + swb[i][t & 1]];
+                    }
+                    cs[i] = fmaf(csw, (av[0] + av[1]) + (av[2] + av[3]), cs[i]);
+                    af[i] = ppk_seq::to_bf16x4(av);
+                    bf[i] = ppk_seq::to_bf16x4(bv);
+                }
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x8bf16_1k(af[i], bf[j], acc[i][j], 0, 0, 0);
+            }
+        } else {
 #pragma unroll
         for (int s = 0; s < BK / 2; ++s) {
             float a[2], b[2];
@@ -326,6 +362,7 @@ __global__ __launch_bounds__(256) void k_tn128(const GemmArgs g)
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
         }
         cur ^= 1;
     }
@@ -552,7 +589,8 @@ int gemm_csum(int transA, int transB, int64_t M, int64_t N, int64_t K, float alp
     g.csum = csum;
     if (tn_fast) {
         ppk::ProfScope prof(PK_GEMM_TN128, 2.0 * (double)M * (double)N * (double)K, stream);
-        k_tn128<<<dim3((unsigned)cdiv(N, 128), (unsigned)cdiv(M, 128), (unsigned)g.ksplit), dim3(256), 0, stream>>>(g);
+        if (ppk::mfma_mode() == 1) k_tn128<true><<<dim3((unsigned)cdiv(N, 128), (unsigned)cdiv(M, 128), (unsigned)g.ksplit), dim3(256), 0, stream>>>(g);
+        else k_tn128<false><<<dim3((unsigned)cdiv(N, 128), (unsigned)cdiv(M, 128), (unsigned)g.ksplit), dim3(256), 0, stream>>>(g);
         PPK_CHECK_LAUNCH("k_tn128");
     } else {
         dispatch(gb, 1, pl.tile, a_kc, b_kc, 2.0 * (double)M * (double)N * (double)K, stream);

@@ -73,3 +73,33 @@ def test_bf16_operand_step_within_stated_tolerance(bundles):
         assert err <= GRAD_TOL, (n, err)
         assert cos >= GRAD_COS, (n, cos)
     print(f'bundles {bundles}: loss fp32 {l32:.6f} bf16 {l16:.6f} (rel {abs(l16 - l32) / abs(l32):.2e}), worst gradient error {worst:.2e} of max')
+
+
+@pytest.mark.parametrize('M,N,K', [(384, 256, 9001), (1536, 512, 20011), (200, 196, 8200)])
+def test_tn_weight_gradient_gemm_is_the_product_of_bf16_rounded_operands(M, N, K):
+    """Sharp statement of what mode 1 computes in k_tn128: C = bf16(A)^T . bf16(B) accumulated in fp32 (checked
+    against the fp64 product of the rounded operands to fp32-accumulation accuracy); the column sums (the bias
+    gradient) stay fp32 sums of the unrounded A."""
+    from paccmann_polymer_amd import _C
+    lib = _C.lib
+    torch.manual_seed(M + N + K)
+    A = torch.randn(K, M, device='cuda')
+    B = torch.randn(K, N, device='cuda')
+    C = torch.full((M, N), float('nan'), device='cuda')
+    cs = torch.full((M,), float('nan'), device='cuda')
+    wsb = lib.ppk_gemm_f32_workspace_bytes(M, N, K)
+    ws = torch.empty(max(wsb, 1), dtype=torch.uint8, device='cuda')
+    assert lib.ppk_mfma_mode(1) == 1
+    try:
+        _C.check(lib.ppk_gemm_tn_colsum_f32(M, N, K, _C.p(A), M, _C.p(B), N, _C.p(C), N, _C.p(cs), _C.p(ws), wsb, _C.stream()))
+        torch.cuda.synchronize()
+    finally:
+        lib.ppk_mfma_mode(0)
+    Ab, Bb = A.bfloat16().double(), B.bfloat16().double()
+    # the K tail (< 32 rows of the last slab) is multiplied unrounded: allow it its rounding difference
+    ref = Ab.T @ Bb
+    bound = 2e-6 * ((Ab.abs().T @ Bb.abs()).max().item() + 1.0) + 2.0 ** -7 * 32 * float(A.abs().max() * B.abs().max())
+    assert (C.double() - ref).abs().max().item() <= bound
+    exact = A.double().T @ B.double()
+    assert (C.double() - exact).abs().max().item() > 0.0
+    assert (cs.double() - A.double().sum(0)).abs().max().item() <= 2e-6 * A.abs().double().sum(0).max().item()

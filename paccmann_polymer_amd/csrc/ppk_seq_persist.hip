@@ -619,6 +619,7 @@ int seq_persist_mode(int mode)
 bool seq_fwd_persist_ok(int64_t T, int64_t B, int64_t NT, int64_t H, int64_t L, int64_t W, int64_t D, int64_t ks, int64_t ldcs)
 {
     if (force_mode() == 0) return false;
+    if (force_mode() == -1 && B < ppk::SEQP_AUTO_MIN_B) return false;       // auto: below this the per-layer-step launches are faster (tools/persist_threshold.py)
     if (T < 1 || T > MAXT || L < 1 || L > MAXL || H % 32 || H > 2048 || ks % 32 || ks > 512 || NT >= (1LL << 31) || B > (1 << 24)) return false;
     if (ldcs < 3 + W || ldcs % 32) return false;
     const int64_t DW4 = (D * W + 3) / 4 * 4;

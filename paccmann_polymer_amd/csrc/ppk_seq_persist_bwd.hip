@@ -696,6 +696,7 @@ namespace ppk {
 bool seq_bwd_persist_ok(int64_t T, int64_t B, int64_t NT, int64_t H, int64_t L, int64_t W, int64_t D, int64_t ks, int64_t ldcs)
 {
     if (seq_persist_mode(-2) == 0) return false;
+    if (seq_persist_mode(-2) == -1 && B < ppk::SEQP_AUTO_MIN_B) return false;
     if (T < 1 || T > MAXT || L < 1 || L > MAXL || H % 32 || H > 2048 || ks % 32 || ks > 64 || NT >= (1LL << 31) || B > (1 << 24)) return false;
     if (ldcs < 3 + W || ldcs % 32 || ldcs > 512) return false;
     if (NT * 3 * H * 4 >= (1LL << 31)) return false;                // byte offsets of the buffer stores inside one layer's dgi

@@ -17,3 +17,15 @@ def pytest_configure(config):
 @pytest.fixture(scope='session')
 def golden_dir():
     return GOLDEN
+
+
+@pytest.fixture(params=['per_step_launches', 'persistent_launch'])
+def seq_schedule(request):
+    """Runs a test under both launch schedules of the K1 sequence entry points (ppk_seq_persist_mode 0 / 1): auto
+    mode picks the persistent launch only from batch 1024 up, so the parity cases (small batches) would otherwise
+    never reach it.  Mode 1 falls back to the per-step launches where a shape is unsupported."""
+    from paccmann_polymer_amd import _C
+    mode = 0 if request.param == 'per_step_launches' else 1
+    assert _C.lib.ppk_seq_persist_mode(mode) == mode
+    yield request.param
+    _C.lib.ppk_seq_persist_mode(-1)

@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 import torch
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures('seq_schedule')]
 
 PARAMS = dict(vocab_size=18, embedding_size=9, rnn_cell_size=40, n_layers=2, stack_width=7, stack_depth=4,
               latent_dim=6, dropout=0.0, padding_index=0, batch_size=1, batch_mode='packed')

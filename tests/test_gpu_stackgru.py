@@ -11,7 +11,7 @@ import pytest
 import torch
 from torch.nn.utils.rnn import pack_sequence
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures('seq_schedule')]
 
 SMALL = dict(vocab_size=20, embedding_size=16, rnn_cell_size=32, n_layers=2, stack_width=6, stack_depth=5,
              latent_dim=8, dropout=0.0, padding_index=0, batch_size=1, batch_mode='packed')

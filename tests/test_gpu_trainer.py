@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 import torch
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures('seq_schedule')]
 
 PARAMS = dict(vocab_size=30, embedding_size=16, rnn_cell_size=32, n_layers=2, stack_width=6, stack_depth=5,
               latent_dim=8, dropout=0.0, padding_index=0)

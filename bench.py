@@ -62,68 +62,129 @@ def to_device_batch(seqs, gs, device):
     return dev(enc), dev(enc), dev(tgt), g_flat
 
 
-def cpu_baseline(seed=0, n_bundles=4, bundle_nodes=16):
-    """Reference-semantics CPU step (the oracle: per-timestep nn.GRU StackGRU VAE + loop-for-loop
-    graph_loss in C + analytic gradient) on a bounded sample: config 1b, batch 64 = 4 bundles x 16."""
+def cpu_baseline(seed=0, bundle_nodes=16):
+    """Reference-semantics CPU step on the host cores at BASELINE configs[0] (batch 64, fp32, Adam lr 1e-4), split as
+    BASELINE.md section 3 asks: the sequence part (the oracle's per-timestep nn.GRU StackGRU VAE: forward, backward,
+    Adam) timed once, and the graph loss (forward + backward w.r.t. z) timed in three restatements on two graphs:
+      python loop  — term by term with torch autograd, as the reference's graph_loss does it (oracle.graph_loss_loop_torch)
+      vectorised   — closed form in a few torch ops with autograd (oracle.graph_loss_vectorised_torch)
+      C port       — oracle/graph_loss_ref.c with its analytic gradient
+      1a: one dense 64-node graph (Floyd–Warshall hops of a G(64, 192) random graph); 1b: 4 bundles x 16 nodes.
+    `value` is the reference as written on how it batches its graphs (python loop, 1b); the others are in `variants`.
+    A bounded sample: one pass of each leg (the 1a python loop alone is ~20 s)."""
     from oracle import stackgru_ref as R
     from oracle import graph_loss_oracle as O
+    from paccmann_polymer_amd.data_prep import hop_distance_matrix
     rng = np.random.default_rng(seed)
     torch.manual_seed(seed)
+    n_bundles = 64 // bundle_nodes
     seqs, gs, sizes = synth_batch(rng, n_bundles, bundle_nodes)
+    B = len(seqs)
+    # 1a: G(n = 64, m = 192) random graph, re-drawn until connected
+    while True:
+        pairs = set()
+        while len(pairs) < 192:
+            u, v = (int(x) for x in rng.integers(0, B, size=2))
+            if u != v:
+                pairs.add((min(u, v), max(u, v)))
+        g_dense = hop_distance_matrix(np.asarray(sorted(pairs), dtype=np.int64).T, B, order='networkx')
+        if np.isfinite(g_dense).all():
+            break
     vae = R.TeacherVAERef(R.StackGRUEncoderRef(PARAMS), R.StackGRUDecoderRef(PARAMS))
     opt = torch.optim.Adam(vae.parameters(), lr=1e-4)
     enc = pack_sequence(seqs, enforce_sorted=False)
     tgt = pack_sequence([torch.cat([s[1:], torch.zeros(1, dtype=torch.int64)]) for s in seqs], enforce_sorted=False)
-    B = len(seqs)
     eps = torch.randn(B, PARAMS['latent_dim'])
+    dz_inject = torch.zeros(B, PARAMS['latent_dim'])
+    zs = []
 
-    def step():
+    def seq_step():
         opt.zero_grad()
         dec_loss, mu, logvar, z = R.train_step_ref(vae, enc, enc, tgt, eps)
         z2 = z.squeeze(0)
-        gl, dz = O.graph_loss_segmented_c(z2.detach().numpy(), gs, sizes, acc_fp32=True)
-        # graph_gamma = 1: inject the oracle's analytic d(graph_loss)/dz
-        (dec_loss + (z2 * torch.tensor(dz, dtype=torch.float32)).sum()).backward()
+        zs.append(z2.detach().clone())
+        (dec_loss + (z2 * dz_inject).sum()).backward()          # graph_gamma = 1: the graph loss enters through dL/dz
         opt.step()
-    step()                      # warm-up
+    seq_step()                                                   # warm-up
     t0 = time.perf_counter()
-    n = 0
-    while time.perf_counter() - t0 < 12.0 and n < 8:
-        step()
-        n += 1
-    dt = (time.perf_counter() - t0) / n
-    return dict(value=B / dt, unit='samples/s', cores=torch.get_num_threads(), kind='port',
-                sample=f'config 1b: batch {B} = {n_bundles} bundles x {bundle_nodes} SMILES (len 20..100), '
-                       f'{n} full steps (fwd+bwd+Adam) of the oracle (torch nn.GRU per timestep + C graph_loss loop), '
-                       f'{dt:.2f} s/step')
+    seq_step()
+    seq_step()
+    t_seq = (time.perf_counter() - t0) / 2
+    z0 = zs[-1]
+
+    def timed(fn):
+        t0 = time.perf_counter()
+        fn()
+        return time.perf_counter() - t0
+
+    def torch_leg(fn, graphs, seg):
+        def run():
+            z = z0.clone().requires_grad_(True)
+            off, total = 0, 0.0
+            for g, n in zip(graphs, seg):
+                total = total + fn(z[off:off + n], torch.tensor(g, dtype=torch.float32))
+                off += n
+            total.backward()
+        return run
+
+    def c_leg(graphs, seg):
+        return lambda: O.graph_loss_segmented_c(z0.numpy(), graphs, seg, acc_fp32=True)
+    legs = {
+        'python_loop_1b': torch_leg(O.graph_loss_loop_torch, gs, sizes),
+        'python_loop_1a': torch_leg(O.graph_loss_loop_torch, [g_dense], [B]),
+        'vectorised_1b': torch_leg(O.graph_loss_vectorised_torch, gs, sizes),
+        'vectorised_1a': torch_leg(O.graph_loss_vectorised_torch, [g_dense], [B]),
+        'c_port_1b': c_leg(gs, sizes),
+        'c_port_1a': c_leg([g_dense], [B]),
+    }
+    variants = {}
+    for name, fn in legs.items():
+        if not name.startswith('python_loop'):
+            fn()                                                 # warm-up of the cheap legs
+        t = timed(fn)
+        variants[name] = dict(samples_per_s=round(B / (t_seq + t), 3), graph_loss_s=round(t, 4), step_s=round(t_seq + t, 4))
+    cores = torch.get_num_threads()
+    return dict(value=variants['python_loop_1b']['samples_per_s'], unit='samples/s', cores=cores, kind='port',
+                sample=f'configs[0]: batch {B}, len 20..100, one pass per leg; step = sequence part (oracle nn.GRU-per-timestep '
+                       f'StackGRU VAE fwd+bwd+Adam, {t_seq:.2f} s, mean of 2) + graph loss fwd+bwd; value = python-loop '
+                       f'restatement on 1b ({n_bundles} bundles x {bundle_nodes}); torch threads {cores} (the python loop itself is single-threaded)',
+                sequence_part_s=round(t_seq, 4), variants=variants)
 
 
 def pmc_traffic(kernel):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes of this same command
-    (profiles/r01_bench_pmc_v*.txt: FETCH_SIZE and WRITE_SIZE in KiB summed over the run's launches; on gfx950
-    FETCH_SIZE counts half of the wide streaming reads, so it is doubled — MI355X_MICROARCH.md, HBM section).
-    The counters cannot be collected inside the timed run; the file is the newest committed pass."""
+    (profiles/rNN_bench_pmc_v*.txt, written by tools/collect_profiles.sh: FETCH_SIZE and WRITE_SIZE in KiB summed over
+    the run's launches; on gfx950 FETCH_SIZE counts half of the wide streaming reads, so it is doubled —
+    MI355X_MICROARCH.md, HBM section).  The counters cannot be collected inside the timed run; the newest committed pass
+    is used ONLY when its `# source_hash` line equals the hash of the kernel sources of this tree
+    (tools/source_hash.py) — a profile of other code is refused and `traffic` stays null."""
     import glob
     import re
+    from tools.source_hash import source_hash
     files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r*_bench_pmc_v*.txt')),
                    key=lambda f: [int(x) for x in re.findall(r'\d+', os.path.basename(f))])
     if not files:
         return {}
     short = kernel.split('<')[0]
-    vals, section = {}, None
+    vals, section, file_hash = {}, None, None
     for line in open(files[-1]):
         f = line.split()
-        if len(f) >= 3 and f[0] == 'kernel' and f[-1] in ('FETCH_SIZE', 'WRITE_SIZE'):
+        if len(f) == 3 and f[0] == '#' and f[1] == 'source_hash':
+            file_hash = f[2]
+        elif len(f) >= 3 and f[0] == 'kernel' and f[-1] in ('FETCH_SIZE', 'WRITE_SIZE'):
             section = f[-1]
         elif line.startswith('kernel'):
             section = None
         elif section and len(f) == 3 and f[0] == short:
             vals[section] = (float(f[2]), int(f[1]))
+    here = source_hash()
+    if file_hash != here:
+        return dict(traffic_note=f'{os.path.basename(files[-1])} was taken from sources {file_hash}, this tree is {here}: refused')
     if 'FETCH_SIZE' not in vals or 'WRITE_SIZE' not in vals:
         return {}
     (fk, fl), (wk, wl) = vals['FETCH_SIZE'], vals['WRITE_SIZE']
     return dict(traffic=round(2.0 * fk * 1024 / fl + wk * 1024 / wl), traffic_unit='HBM bytes per launch',
-                traffic_source=os.path.basename(files[-1]))
+                traffic_source=os.path.basename(files[-1]), traffic_source_hash=file_hash)
 
 
 def main():
@@ -241,6 +302,7 @@ def main():
     roofline = dict(bound='mfma' if is_gemm else 'hbm', achieved=round(achieved, 2), peak=peak,
                     unit='TFLOP/s' if is_gemm else 'GB/s', frac=round(achieved / peak, 4), traffic=None,
                     kernel=top['kernel'], launches_per_step=top['launches'],
+                    profiled_launches_per_step=sum(d['launches'] for d in kinds),
                     avg_launch_us=round(top['ms'] * 1e3 / top['launches'], 2),
                     step_breakdown_ms={d['kernel']: round(d['ms'], 3) for d in kinds})
 

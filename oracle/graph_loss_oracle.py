@@ -194,3 +194,58 @@ def graph_loss_closed_form(z, g_dists):
     m = (i < j) & (r >= j)
     row = f(G[i, j] - D[i, r], D[i, j], D[i, r])[m].sum()
     return float((col + row) / D.max())
+
+
+# --------------------------------------------------------------------------
+# torch restatements WITH autograd: what the reference's step actually pays for on the CPU (the loss is built term
+# by term from 0-dim tensors, graph_constrained_loss.py:44-66, and differentiated by autograd).  Timing legs of
+# bench.py's cpu_baseline only.
+# --------------------------------------------------------------------------
+def graph_loss_loop_torch(z, g_dists):
+    """Term-for-term restatement (same terms, same accumulation order, same torch ops per term: subtraction,
+    pow / relu, division by the max, in-place add into a 0-dim tensor) of graph_constrained_loss.py:25-67.
+    z: [N, Z] torch tensor (may require grad), g_dists: [N, N] torch tensor."""
+    import torch
+    D = torch.cdist(z, z, p=2.0).squeeze()                      # :13-22
+    if D.shape != g_dists.shape:
+        raise ValueError()
+    top = D.max()                                               # :40
+    n = len(D)
+    total = torch.tensor(0.0)
+
+    def term(delta, a, b):                                      # :4-10
+        if delta == 0:
+            return torch.pow(a - b, 2)
+        if delta > 0:
+            return torch.relu(b - a)
+        return torch.relu(a - b)
+
+    for i in range(n):
+        for j in range(i + 1, n):
+            a, ga = D[i, j], g_dists[i, j]
+            for r in range(i, n):                               # down column j from row i (:49-57)
+                if r != j:
+                    total += term(ga - g_dists[r, j], a, D[r, j]) / top
+            for c in range(j, n):                               # along row i from column j; the "graph" value read
+                b = D[i, c]                                     # here is the LATENT distance (:61-62, SURVEY Quirk A)
+                total += term(ga - b, a, b) / top
+    return total
+
+
+def graph_loss_vectorised_torch(z, g_dists):
+    """Closed form of the same sum in a handful of torch tensor ops, with autograd."""
+    import torch
+    D = torch.cdist(z, z, p=2.0).squeeze()
+    if D.shape != g_dists.shape:
+        raise ValueError()
+    n = len(D)
+    G = g_dists.to(D.dtype)
+    idx = torch.arange(n)
+    i, j, r = torch.meshgrid(idx, idx, idx, indexing='ij')
+
+    def f(delta, a, b):
+        return torch.where(delta == 0, (a - b) ** 2, torch.where(delta > 0, torch.relu(b - a), torch.relu(a - b)))
+
+    col = (f(G[i, j] - G[r, j], D[i, j], D[r, j]) * ((i < j) & (r >= i) & (r != j))).sum()
+    row = (f(G[i, j] - D[i, r], D[i, j], D[i, r]) * ((i < j) & (r >= j))).sum()
+    return (col + row) / D.max()

@@ -67,3 +67,17 @@ def test_term_count_closed_form_small_n():
         for j in range(i + 1, n):
             cnt += sum(1 for r in range(i, n) if r != j) + (n - j)
     assert cnt == n * n * (n - 1) // 2
+
+
+@pytest.mark.parametrize('name', ['graphreg_dense_N5_Z3', 'graphreg_dense_N8_Z16', 'graphreg_floatG_N10_Z4', 'graphreg_dense_N16_Z16'])
+def test_torch_autograd_restatements_match_reference(name):
+    """The two timing legs of bench.py's cpu_baseline (term-by-term torch loop, vectorised closed form), loss and
+    autograd gradient, against the reference's own outputs."""
+    import torch
+    g = np.load(os.path.join(GOLDEN, name + '.npz'))
+    for fn in (O.graph_loss_loop_torch, O.graph_loss_vectorised_torch):
+        z = torch.tensor(g['z'], dtype=torch.float32, requires_grad=True)
+        loss = fn(z, torch.tensor(g['G'], dtype=torch.float32))
+        loss.backward()
+        assert abs(float(loss.detach()) - float(g['loss'])) <= 1e-5 * abs(float(g['loss']))
+        assert rel(z.grad.numpy(), g['dz']) <= 1e-4

@@ -97,7 +97,9 @@ int ppk_graphreg_dense_bwd(const float* z, int64_t ldz, const int64_t* seg_ptr, 
  * (rowptr, col, eid) = CSR (ppk_csr_build, no self loops, no normalisation) of the
  * SYMMETRISED edge list: entry ids e in [0, E) for u->v and E + e for v->u; rev [2E]
  * maps each entry to its reverse entry.  Anchors [a0, a1) let ranks own node ranges:
- * dist -> (MAX-all-reduce *max_ptr) -> terms -> (SUM-all-reduce *sum_ptr) -> finish;
+ * dist -> (MAX-all-reduce *max_ptr) -> terms -> (SUM-all-reduce sum_ptr[0..1]: the sum S and the number of edges
+ * whose distance equals the maximum — the gradient through the normaliser is shared evenly by them, as torch's
+ * backward of `z_dists.max()`, graph_constrained_loss.py:40, does) -> finish;
  * bwd yields this rank's partial dz [N, zdim] (reduce-scatter across ranks).
  * dist / dist_once with eid == NULL take g as [2E] attributes already in CSR order (permuted once per graph). */
 size_t ppk_graphreg_sparse_workspace_bytes(int64_t N, int64_t E, int64_t zdim);

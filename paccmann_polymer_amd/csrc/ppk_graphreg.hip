@@ -17,7 +17,7 @@
 //              by anchor a, and the anchor's partial sum of f (fp64).
 //   k_segsum : S_k = sum of anchor partials (fixed order), loss_k = S_k / M_k
 //   k_total  : loss = sum_k loss_k (fixed order)
-//   k_dz     : dz_p = up * sum_q [ (T[p][q] + T[q][p]) / M_k - S_k/M_k^2 [pq = argmax] ] (z_p - z_q)/D_pq
+//   k_dz     : dz_p = up * sum_q [ (T[p][q] + T[q][p]) / M_k - S_k/M_k^2 [D_pq = M_k] / #ties ] (z_p - z_q)/D_pq
 // Everything is a fixed-order reduction: results are bitwise reproducible.
 #include "ppk_common.h"
 
@@ -239,7 +239,7 @@ __global__ __launch_bounds__(256) void k_terms(const float* __restrict__ D, cons
         Grow_f[x] = (float)gr;
         fits &= (GT)(float)gc == gc || gc != gc;       // NaN compares as "equal" either way
         fits &= (GT)(float)gr == gr || gr != gr;
-        if (x > a && d == M) atomicMin(&segArg[s.seg], (unsigned long long)a * (unsigned long long)n + x);
+        if (x > a && d == M) atomicAdd(&segArg[s.seg], 1ull);      // number of tied maxima (integer: order-free)
     }
     double S;
     if (sizeof(GT) == sizeof(float) || __syncthreads_and(fits)) {
@@ -324,15 +324,17 @@ __global__ __launch_bounds__(256) void k_dz(const float* __restrict__ z, long lo
     const float M = __uint_as_float(segM[s.seg]);
     const float invM = 1.0f / M;
     const float gmax = (float)(-segS[s.seg] / ((double)M * (double)M));
-    const unsigned long long arg = segArg[s.seg];
-    const int ai = (int)(arg / (unsigned long long)n), aj = (int)(arg % (unsigned long long)n);
+    // d loss / d max, shared EVENLY by the tied maxima (torch's backward of a full max(), which the reference's
+    // `z_dists.max()` runs, graph_constrained_loss.py:40): segArg = number of pairs p < q with D_pq == M
+    const unsigned long long ties = segArg[s.seg];
+    const float gshare = ties > 0 ? (float)((double)gmax / (double)ties) : 0.0f;
     for (int q = threadIdx.x; q < n; q += blockDim.x) {
         float c = 0.0f;
         if (q != a && n >= 2) {
             const float d = D[s.mat0 + (long long)a * n + q];
             if (d != 0.0f) {
                 float w = (T[s.mat0 + (long long)a * n + q] + T[s.mat0 + (long long)q * n + a]) * invM;
-                if ((a == ai && q == aj) || (a == aj && q == ai)) w += gmax;
+                if (d == M) w += gshare;
                 c = up * w / d;
             }
         }
@@ -417,7 +419,7 @@ int ppk_graphreg_dense_fwd(const float* z, int64_t ldz, const void* g, int g_dty
     if (g_dtype != PPK_F32 && g_dtype != PPK_F64) PPK_FAIL(PPK_ERR_UNSUP, "graphreg_dense_fwd: g_dtype must be PPK_F32 or PPK_F64");
     DenseWs w = dense_ws_carve(workspace, n_seg, n_total, sum_n2);
     PPK_HIP(hipMemsetAsync(w.segM, 0, sizeof(unsigned int) * (size_t)n_seg, stream));
-    PPK_HIP(hipMemsetAsync(w.segArg, 0xff, sizeof(unsigned long long) * (size_t)n_seg, stream));
+    PPK_HIP(hipMemsetAsync(w.segArg, 0, sizeof(unsigned long long) * (size_t)n_seg, stream));
     if (n_seg == 1 && max_n >= 128 && max_n == n_total) {
         const unsigned t = (unsigned)((n_total + 63) / 64);
         k_dist_tiled<<<dim3(t, t), dim3(256), 0, stream>>>(z, ldz, (int)zdim, (int)n_total, w.D, w.segM);

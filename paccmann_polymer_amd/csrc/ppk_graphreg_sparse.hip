@@ -191,11 +191,13 @@ __global__ __launch_bounds__(256) void k_sp_dist_once(const float* __restrict__ 
 // the entries' contributions to S are summed per wave in a fixed order (Spart[wave]).
 __global__ __launch_bounds__(256) void k_sp_terms(const long long* __restrict__ rowptr, const long long* __restrict__ col,
                                                   const float* __restrict__ dcsr, const float* __restrict__ gcsr,
-                                                  long long a0, long long a1, float* __restrict__ T, double* __restrict__ Spart)
+                                                  long long a0, long long a1, float* __restrict__ T, double* __restrict__ Spart,
+                                                  const unsigned int* __restrict__ Mbits, unsigned long long* __restrict__ ties)
 {
     const long long gw = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
     const long long e = rowptr[a0] + (long long)blockIdx.x * 256 + threadIdx.x;
     double S = 0.0;
+    int tie = 0;
     if (e < rowptr[a1]) {
         const long long a = row_of_near(rowptr, a0, a1, rowptr[a0] + (long long)blockIdx.x * 256, e);
         const long long j0 = rowptr[a];
@@ -203,6 +205,9 @@ __global__ __launch_bounds__(256) void k_sp_terms(const long long* __restrict__ 
         const long long idx = col[e];
         const float dx = dcsr[e], gx = gcsr[e];
         float t = 0.f, Sx = 0.f;
+        // an edge whose distance IS the (global) maximum, counted once, by the owner of its lower endpoint: the
+        // gradient through the normaliser is shared evenly by such edges (torch's backward of a full max())
+        tie = idx > a && dx == __uint_as_float(Mbits[0]);
         // ONE walk over the anchor's neighbour list: every partner y meets x in exactly one role (three separate walks,
         // one per raster role, read the list up to three times: 2.6 ms against 1.x ms on 1 M nodes / 10 M edges).
         //   idx < a :  idy > idx  column raster, x = i, y = r        f(G_x - G_y ; D_x, D_y)   adds to S, t += f'
@@ -229,7 +234,11 @@ __global__ __launch_bounds__(256) void k_sp_terms(const long long* __restrict__ 
         S = (double)Sx;
     }
     S = ppk_wave_sum_d(S);
-    if ((threadIdx.x & 63) == 0) Spart[gw] = S;
+    const unsigned long long nt = __popcll(__ballot(tie));
+    if ((threadIdx.x & 63) == 0) {
+        Spart[gw] = S;
+        if (nt) atomicAdd(ties, nt);                        // integer count: independent of the order of arrival
+    }
 }
 
 // S = sum of the per-wave partials of the local anchors' entries, in a fixed order: SUM_BLOCKS blocks each
@@ -250,14 +259,17 @@ __global__ __launch_bounds__(256) void k_sp_sum(const double* __restrict__ Spart
     __syncthreads();
     if (threadIdx.x == 0) slice_sum[blockIdx.x] = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
 }
-__global__ __launch_bounds__(256) void k_sp_sum2(const double* __restrict__ slice_sum, double* __restrict__ S_out)
+// S_out[0] = S; S_out[1] = number of tied maximal edges counted by this rank (as a double, so that ONE sum
+// all-reduce over both words makes them global when the anchors are sharded)
+__global__ __launch_bounds__(256) void k_sp_sum2(const double* __restrict__ slice_sum, double* __restrict__ S_out,
+                                                 const unsigned long long* __restrict__ ties)
 {
     __shared__ double wsum[4];
     double acc = threadIdx.x < SUM_BLOCKS ? slice_sum[threadIdx.x] : 0.0;
     acc = ppk_wave_sum_d(acc);
     if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = acc;
     __syncthreads();
-    if (threadIdx.x == 0) S_out[0] = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
+    if (threadIdx.x == 0) { S_out[0] = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]); S_out[1] = (double)ties[0]; }
 }
 __global__ void k_sp_loss(const double* __restrict__ S, const unsigned int* __restrict__ Mbits, float* __restrict__ loss)
 {
@@ -277,7 +289,7 @@ __global__ __launch_bounds__(256) void k_sp_coef(long long N, const long long* _
     const float up = dloss[0];
     const float M = __uint_as_float(Mbits[0]);
     const float invM = 1.0f / M;
-    const float gmax = (float)(-S[0] / ((double)M * (double)M));
+    const float gmax = S[1] > 0.0 ? (float)(-S[0] / ((double)M * (double)M) / S[1]) : 0.0f;      // per tied maximal edge
     const long long p = row_of_near(rowptr, 0, N, (long long)blockIdx.x * 256, j);
     const long long a = col[j];
     const bool own_p = p >= a0 && p < a1, own_a = a >= a0 && a < a1;
@@ -524,12 +536,14 @@ int ppk_graphreg_sparse_terms(int64_t N, int64_t E, const int64_t* rowptr, const
     if (ws_bytes < sp_ws_bytes(N, 2 * E, 0)) PPK_FAIL(PPK_ERR_WS, "graphreg_sparse_terms: workspace too small");
     SpWs w = sp_carve(workspace, N, 2 * E, 0);
     const long long nwaves = (long long)sp_nwaves(2 * E);
+    unsigned long long* ties = (unsigned long long*)(w.S + 2);         // third word of the 256-byte S slot
+    PPK_HIP(hipMemsetAsync(ties, 0, sizeof(unsigned long long), stream));
     k_sp_terms<<<dim3((unsigned)(nwaves / 4)), dim3(256), 0, stream>>>((const long long*)rowptr, (const long long*)col, w.dcsr, w.gcsr,
-                                                                      a0, a1, w.T, w.Spart);
+                                                                      a0, a1, w.T, w.Spart, w.Mbits, ties);
     PPK_CHECK_LAUNCH("k_sp_terms");
     k_sp_sum<<<dim3(SUM_BLOCKS), dim3(256), 0, stream>>>(w.Spart, (const long long*)rowptr, a0, a1, w.slice);
     PPK_CHECK_LAUNCH("k_sp_sum");
-    k_sp_sum2<<<dim3(1), dim3(256), 0, stream>>>(w.slice, w.S);
+    k_sp_sum2<<<dim3(1), dim3(256), 0, stream>>>(w.slice, w.S, ties);
     PPK_CHECK_LAUNCH("k_sp_sum2");
     return PPK_OK;
 }

@@ -119,7 +119,7 @@ class _SparseGraphLoss(torch.autograd.Function):
         _C.check(_lib.ppk_graphreg_sparse_terms(N, E, _C.p(graph.rowptr), _C.p(graph.col), a0, a1, _C.p(ws), wsb, st))
         if group is not False:
             off = _lib.ppk_graphreg_sparse_sum_ptr(_C.p(ws), N, E) - base
-            s = ws[off:off + 8].view(torch.float64)
+            s = ws[off:off + 16].view(torch.float64)          # [S, number of tied maximal edges]: both are sums over ranks
             dist.all_reduce(s, op=dist.ReduceOp.SUM, group=group)
         loss = torch.empty(1, dtype=torch.float32, device=dev)
         _C.check(_lib.ppk_graphreg_sparse_finish(N, E, _C.p(loss), _C.p(ws), wsb, st))

@@ -328,3 +328,47 @@ def test_hop_matrices_bad_label_raises_without_sync():
     from paccmann_polymer_amd.data_prep import hop_distance_matrices_device
     with pytest.raises(IndexError):
         hop_distance_matrices_device([np.array([[0, 1], [1, 5]])], [3], device='cuda')
+
+
+@pytest.mark.parametrize('copies', [2, 3])
+def test_max_normaliser_ties_split_evenly_dense_and_sparse(copies):
+    """`z_dists.max()` (graph_constrained_loss.py:40) with TIED maxima: torch's backward of a full `max()` splits the
+    gradient evenly over the tied entries.  Duplicate latent rows give exact ties (and zero distances between the
+    copies, where cdist's backward is 0).  K4 (dense) and K5 (sparse, complete edge set) against torch autograd in
+    fp64 through the vectorised restatement of the same loss."""
+    from oracle import graph_loss_oracle as O
+    from paccmann_polymer_amd.graph_loss_sparse import SparseRelationGraph, graph_loss_sparse
+    import paccmann_polymer_amd as P
+    rng = np.random.default_rng(11 + copies)
+    far = np.array([[0., 0., 0., 0.], [6., 8., 0., 0.]], dtype=np.float32)           # distance 10: the maximum
+    near = (rng.integers(-2, 3, size=(5, 4)) + np.array([3., 4., 0., 0.])).astype(np.float32)
+    z = np.concatenate([np.tile(far, (copies, 1)), near])
+    n = len(z)
+    G = rng.integers(1, 4, size=(n, n)).astype(np.float64)
+    G = np.triu(G, 1) + np.triu(G, 1).T
+    z64 = torch.tensor(z, dtype=torch.float64, requires_grad=True)
+    D = torch.cdist(z64, z64)
+    assert int((D == D.max()).sum()) == 2 * copies * copies                         # the tie is real
+    ref = O.graph_loss_vectorised_torch(z64, torch.tensor(G))
+    ref.backward()
+    dref = z64.grad.numpy()
+    # the C oracle shares the gradient the same way (dense and sparse restatements)
+    lo, dzo = O.graph_loss_c(z, G)
+    assert abs(lo - float(ref.detach())) <= 1e-5 * abs(float(ref.detach())) and rel(torch.tensor(dzo), torch.tensor(dref)) <= 1e-4
+    iu = np.triu_indices(len(z), 1)
+    lso, dzso = O.graph_loss_sparse_c(z, np.stack(iu).astype(np.int64), G[iu])
+    assert abs(lso - float(ref.detach())) <= 1e-5 * abs(float(ref.detach())) and rel(torch.tensor(dzso), torch.tensor(dref)) <= 1e-4
+    # dense
+    zt = torch.tensor(z, device='cuda', requires_grad=True)
+    loss = P.graph_loss(zt, torch.tensor(G))
+    loss.backward()
+    assert abs(float(loss.detach()) - float(ref.detach())) <= 1e-5 * abs(float(ref.detach()))
+    assert rel(zt.grad, torch.tensor(dref)) <= 1e-4
+    # sparse, every pair listed once
+    iu = np.triu_indices(n, 1)
+    g = SparseRelationGraph(torch.tensor(np.stack(iu).astype(np.int64)).cuda(), torch.tensor(G[iu], dtype=torch.float32).cuda(), n)
+    zs = torch.tensor(z, device='cuda', requires_grad=True)
+    ls = graph_loss_sparse(zs, g)
+    ls.backward()
+    assert abs(float(ls.detach()) - float(ref.detach())) <= 1e-5 * abs(float(ref.detach()))
+    assert rel(zs.grad, torch.tensor(dref)) <= 1e-4

@@ -292,6 +292,14 @@ int ppk_csr_build(const int64_t* src, const int64_t* dst, int64_t E, int64_t N, 
  * scatter_add).  The backward is the same call on the CSR of the reversed edges. */
 int ppk_spmm_csr(const int64_t* rowptr, const int64_t* col, const float* val, int64_t N, int64_t nnz,
                  const float* x, int64_t ldx, int64_t F, float* out, int64_t ldo, ppk_stream_t stream);
+/* The same product for graphs with hub rows (power-law relation graphs): rows beyond 1024 entries are cut into
+ * 1024-entry chunks, one wavefront per chunk over the whole grid, and a row's partial sums are added in chunk order
+ * (fixed association: bitwise reproducible; short rows exactly as ppk_spmm_csr).  ppk_spmm_csr reduces such a row
+ * with one workgroup.  Workspace: ppk_spmm_csr_workspace_bytes(N, nnz, F). */
+size_t ppk_spmm_csr_workspace_bytes(int64_t N, int64_t nnz, int64_t F);
+int ppk_spmm_csr_ws(const int64_t* rowptr, const int64_t* col, const float* val, int64_t N, int64_t nnz,
+                    const float* x, int64_t ldx, int64_t F, float* out, int64_t ldo, void* workspace, size_t ws_bytes,
+                    ppk_stream_t stream);
 
 /* ---- PReLU and the DeepGraphInfomax loss (reactions_infomax.py:61,67,131-132,251-264) */
 int ppk_prelu_fwd(const float* x, const float* alpha, int64_t rows, int64_t C, float* y, ppk_stream_t stream);

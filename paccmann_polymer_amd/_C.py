@@ -72,6 +72,8 @@ SIGNATURES = {
     'ppk_csr_build_workspace_bytes': (c_sz, [c_i64, c_i64]),
     'ppk_csr_build': (c_int, [ptr, ptr, c_i64, c_i64, c_int, c_int, c_int, ptr, ptr, ptr, ptr, ptr, ptr, ptr, c_sz, ptr]),
     'ppk_spmm_csr': (c_int, [ptr, ptr, ptr, c_i64, c_i64, ptr, c_i64, c_i64, ptr, c_i64, ptr]),
+    'ppk_spmm_csr_workspace_bytes': (c_sz, [c_i64, c_i64, c_i64]),
+    'ppk_spmm_csr_ws': (c_int, [ptr, ptr, ptr, c_i64, c_i64, ptr, c_i64, c_i64, ptr, c_i64, ptr, c_sz, ptr]),
     'ppk_prelu_fwd': (c_int, [ptr, ptr, c_i64, c_i64, ptr, ptr]),
     'ppk_prelu_bwd': (c_int, [ptr, ptr, ptr, c_i64, c_i64, ptr, ptr, ptr]),
     'ppk_dgi_loss_workspace_bytes': (c_sz, [c_i64]),

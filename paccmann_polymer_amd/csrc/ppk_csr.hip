@@ -30,7 +30,9 @@ constexpr int SCAN_BLOCK = 1024;     // elements per scan block (256 threads x 4
 constexpr int SHORT_ROW = 16;
 constexpr int LDS_SORT_MAX = 8192;
 constexpr int FINISH_LONG = 64;      // rows beyond this are finished by k_finish_long
-constexpr int SPMM_LONG = 1024;      // rows beyond this are reduced by a whole workgroup (k_spmm_long)
+constexpr int SPMM_LONG = 1024;      // rows beyond this are reduced by a whole workgroup (k_spmm_long) or, with a workspace, in chunks
+constexpr int SPMM_CHUNK = 1024;     // entries of a long row per wave of k_spmm_chunks
+struct LongRow { long long row; long long base; };      // a long row and the id of its first chunk
 
 inline unsigned grid_for(long long work, unsigned cap = 8192)
 {
@@ -302,14 +304,23 @@ __global__ __launch_bounds__(256) void k_finish_long(const int64_t* __restrict__
 template <int VEC>   // floats per lane per pass (4 -> float4)
 __global__ __launch_bounds__(256) void k_spmm(const long long* __restrict__ rowptr, const long long* __restrict__ col,
                                               const float* __restrict__ val, const float* __restrict__ x, long long ldx,
-                                              long long N, int F, float* __restrict__ out, long long ldo)
+                                              long long N, int F, float* __restrict__ out, long long ldo,
+                                              unsigned long long* __restrict__ long_ctr, LongRow* __restrict__ long_slots)
 {
     const int lane = threadIdx.x & 63;
     const long long wave_global = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
     const long long nwaves = (long long)gridDim.x * 4;
     for (long long i = wave_global; i < N; i += nwaves) {
         const long long b = rowptr[i], e = rowptr[i + 1];
-        if (e - b > SPMM_LONG) continue;                                // k_spmm_long
+        if (e - b > SPMM_LONG) {                                        // k_spmm_long, or (with a list) the chunk kernels
+            if (long_ctr && lane == 0) {
+                // slot number and first chunk id from ONE 64-bit atomic: slots come out sorted by their first chunk
+                const unsigned long long nch = (unsigned long long)((e - b + SPMM_CHUNK - 1) / SPMM_CHUNK);
+                const unsigned long long old = atomicAdd(long_ctr, (1ull << 40) | nch);
+                long_slots[old >> 40] = LongRow{i, (long long)(old & ((1ull << 40) - 1))};
+            }
+            continue;
+        }
         for (int f0 = lane * VEC; f0 < F; f0 += 64 * VEC) {
             if constexpr (VEC == 4) {
                 f32x4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -399,6 +410,66 @@ __global__ __launch_bounds__(1024) void k_spmm_long(const long long* __restrict_
             }
         }
         __syncthreads();
+    }
+}
+
+// Long rows with a workspace (ppk_spmm_csr_ws): a hub's entries are cut into SPMM_CHUNK-entry chunks, ONE WAVE PER CHUNK
+// over the whole grid (a row holding a third of all edges no longer serialises behind one workgroup), partial rows
+// go to part [chunks][F]; k_spmm_long_sum then adds a row's partials in chunk order (fixed association: bitwise
+// reproducible whatever order the rows were listed in).
+template <int VEC>
+__global__ __launch_bounds__(256) void k_spmm_chunks(const long long* __restrict__ rowptr, const long long* __restrict__ col,
+                                                     const float* __restrict__ val, const float* __restrict__ x, long long ldx, int F,
+                                                     const unsigned long long* __restrict__ long_ctr, const LongRow* __restrict__ slots,
+                                                     float* __restrict__ part)
+{
+    const int lane = threadIdx.x & 63;
+    const long long wave_global = (long long)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (long long)gridDim.x * 4;
+    const unsigned long long ctr = long_ctr[0];
+    const long long total = (long long)(ctr & ((1ull << 40) - 1)), nslots = (long long)(ctr >> 40);
+    for (long long c = wave_global; c < total; c += nwaves) {
+        long long lo = 0, hi = nslots;                       // largest slot with base <= c
+        while (hi - lo > 1) { const long long mid = (lo + hi) >> 1; if (slots[mid].base <= c) lo = mid; else hi = mid; }
+        const long long row = slots[lo].row;
+        const long long j0 = rowptr[row] + (c - slots[lo].base) * SPMM_CHUNK;
+        const long long j1 = j0 + SPMM_CHUNK < rowptr[row + 1] ? j0 + SPMM_CHUNK : rowptr[row + 1];
+        for (int f = lane * VEC; f < F; f += 64 * VEC) {
+            if constexpr (VEC == 4) {
+                f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0, a2 = a0, a3 = a0;
+                long long j = j0;
+                for (; j + 3 < j1; j += 4) {
+                    const f32x4 v0 = *(const f32x4*)(x + col[j] * ldx + f);
+                    const f32x4 v1 = *(const f32x4*)(x + col[j + 1] * ldx + f);
+                    const f32x4 v2 = *(const f32x4*)(x + col[j + 2] * ldx + f);
+                    const f32x4 v3 = *(const f32x4*)(x + col[j + 3] * ldx + f);
+                    a0 += val[j] * v0; a1 += val[j + 1] * v1; a2 += val[j + 2] * v2; a3 += val[j + 3] * v3;
+                }
+                for (; j < j1; ++j) a0 += val[j] * *(const f32x4*)(x + col[j] * ldx + f);
+                *(f32x4*)(part + c * F + f) = (a0 + a1) + (a2 + a3);
+            } else {
+                float a0 = 0.f;
+                for (long long j = j0; j < j1; ++j) a0 = fmaf(val[j], x[col[j] * ldx + f], a0);
+                part[c * F + f] = a0;
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_spmm_long_sum(const long long* __restrict__ rowptr, const unsigned long long* __restrict__ long_ctr,
+                                                       const LongRow* __restrict__ slots, const float* __restrict__ part, int F,
+                                                       float* __restrict__ out, long long ldo)
+{
+    const int lane = threadIdx.x & 63;
+    const long long wave_global = (long long)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (long long)gridDim.x * 4;
+    const long long nslots = (long long)(long_ctr[0] >> 40);
+    for (long long s = wave_global; s < nslots; s += nwaves) {
+        const long long row = slots[s].row, base = slots[s].base;
+        const long long nch = (rowptr[row + 1] - rowptr[row] + SPMM_CHUNK - 1) / SPMM_CHUNK;
+        for (int f = lane; f < F; f += 64) {
+            float acc = part[base * F + f];
+            for (long long k = 1; k < nch; ++k) acc += part[(base + k) * F + f];
+            out[row * ldo + f] = acc;
+        }
     }
 }
 
@@ -509,12 +580,47 @@ int ppk_spmm_csr(const int64_t* rowptr, const int64_t* col, const float* val, in
     // algorithmic bytes: one F-row + col + val per entry, one F-row + rowptr per node
     ppk::ProfScope prof(ppk::PK_SPMM, (double)nnz * (4.0 * F + 12.0) + (double)N * (4.0 * F + 8.0), stream);
     const bool vec = (F % 4 == 0) && (ldx % 4 == 0) && (ldo % 4 == 0) && !((uintptr_t)x & 15) && !((uintptr_t)out & 15);
-    if (vec) k_spmm<4><<<dim3(nb), dim3(256), 0, stream>>>((const long long*)rowptr, (const long long*)col, val, x, ldx, N, (int)F, out, ldo);
-    else     k_spmm<1><<<dim3(nb), dim3(256), 0, stream>>>((const long long*)rowptr, (const long long*)col, val, x, ldx, N, (int)F, out, ldo);
+    if (vec) k_spmm<4><<<dim3(nb), dim3(256), 0, stream>>>((const long long*)rowptr, (const long long*)col, val, x, ldx, N, (int)F, out, ldo, nullptr, nullptr);
+    else     k_spmm<1><<<dim3(nb), dim3(256), 0, stream>>>((const long long*)rowptr, (const long long*)col, val, x, ldx, N, (int)F, out, ldo, nullptr, nullptr);
     PPK_CHECK_LAUNCH("k_spmm");
     if (vec) k_spmm_long<4><<<dim3(512), dim3(1024), 0, stream>>>((const long long*)rowptr, (const long long*)col, val, x, ldx, N, (int)F, out, ldo);
     else     k_spmm_long<1><<<dim3(512), dim3(1024), 0, stream>>>((const long long*)rowptr, (const long long*)col, val, x, ldx, N, (int)F, out, ldo);
     PPK_CHECK_LAUNCH("k_spmm_long");
+    return PPK_OK;
+}
+
+// The same product with a workspace: rows beyond 1024 entries are cut into 1024-entry chunks spread over the whole
+// grid (ppk_spmm_csr gives each such row to ONE workgroup: 35 ms when three hubs hold a third of 5 M edges).
+size_t ppk_spmm_csr_workspace_bytes(int64_t N, int64_t nnz, int64_t F)
+{
+    if (N < 1 || nnz < 0 || F < 1) return 0;
+    const size_t slots = (size_t)(nnz / SPMM_LONG + 1), chunks = (size_t)(nnz / SPMM_CHUNK) + slots + 1;
+    return 256 + ppk_align_up(sizeof(LongRow) * slots, 256) + ppk_align_up(sizeof(float) * chunks * (size_t)F, 256);
+}
+
+int ppk_spmm_csr_ws(const int64_t* rowptr, const int64_t* col, const float* val, int64_t N, int64_t nnz,
+                    const float* x, int64_t ldx, int64_t F, float* out, int64_t ldo, void* workspace, size_t ws_bytes, hipStream_t stream)
+{
+    if (N < 1 || F < 1 || nnz < 0) PPK_FAIL(PPK_ERR_SHAPE, "spmm_csr_ws: bad sizes");
+    if (!rowptr || !col || !val || !x || !out || !workspace) PPK_FAIL(PPK_ERR_NULL, "spmm_csr_ws: null pointer");
+    if (ldx < F || ldo < F) PPK_FAIL(PPK_ERR_SHAPE, "spmm_csr_ws: leading dimension < F");
+    if (ws_bytes < ppk_spmm_csr_workspace_bytes(N, nnz, F)) PPK_FAIL(PPK_ERR_WS, "spmm_csr_ws: workspace too small");
+    char* cur = (char*)workspace;
+    unsigned long long* ctr = (unsigned long long*)ppk_carve(cur, 256);
+    LongRow* slots = (LongRow*)ppk_carve(cur, sizeof(LongRow) * (size_t)(nnz / SPMM_LONG + 1));
+    float* part = (float*)cur;
+    PPK_HIP(hipMemsetAsync(ctr, 0, sizeof(unsigned long long), stream));
+    const unsigned nb = (unsigned)((N + 3) / 4 < 65536 * 4 ? (N + 3) / 4 : 65536 * 4);
+    ppk::ProfScope prof(ppk::PK_SPMM, (double)nnz * (4.0 * F + 12.0) + (double)N * (4.0 * F + 8.0), stream);
+    const bool vec = (F % 4 == 0) && (ldx % 4 == 0) && (ldo % 4 == 0) && !((uintptr_t)x & 15) && !((uintptr_t)out & 15);
+    if (vec) k_spmm<4><<<dim3(nb), dim3(256), 0, stream>>>((const long long*)rowptr, (const long long*)col, val, x, ldx, N, (int)F, out, ldo, ctr, slots);
+    else     k_spmm<1><<<dim3(nb), dim3(256), 0, stream>>>((const long long*)rowptr, (const long long*)col, val, x, ldx, N, (int)F, out, ldo, ctr, slots);
+    PPK_CHECK_LAUNCH("k_spmm");
+    if (vec) k_spmm_chunks<4><<<dim3(2048), dim3(256), 0, stream>>>((const long long*)rowptr, (const long long*)col, val, x, ldx, (int)F, ctr, slots, part);
+    else     k_spmm_chunks<1><<<dim3(2048), dim3(256), 0, stream>>>((const long long*)rowptr, (const long long*)col, val, x, ldx, (int)F, ctr, slots, part);
+    PPK_CHECK_LAUNCH("k_spmm_chunks");
+    k_spmm_long_sum<<<dim3(256), dim3(256), 0, stream>>>((const long long*)rowptr, ctr, slots, part, (int)F, out, ldo);
+    PPK_CHECK_LAUNCH("k_spmm_long_sum");
     return PPK_OK;
 }
 

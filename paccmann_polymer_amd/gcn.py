@@ -69,7 +69,10 @@ def _spmm(csr, x, cap):
     x = x.contiguous()
     N, F = rowptr.numel() - 1, x.shape[1]
     out = torch.empty(N, F, dtype=torch.float32, device=x.device)
-    _C.check(_lib.ppk_spmm_csr(_C.p(rowptr), _C.p(col), _C.p(val), N, cap, _C.p(x), x.stride(0), F, _C.p(out), F, _C.stream()))
+    wsb = _lib.ppk_spmm_csr_workspace_bytes(N, cap, F)            # hub rows: chunked over the whole grid
+    ws = _ws(wsb, x.device)
+    _C.check(_lib.ppk_spmm_csr_ws(_C.p(rowptr), _C.p(col), _C.p(val), N, cap, _C.p(x), x.stride(0), F, _C.p(out), F,
+                                  _C.p(ws), wsb, _C.stream()))
     return out
 
 

@@ -166,3 +166,38 @@ def test_full_size_csr_and_spmm_vs_torch_on_device():
     ref = torch.zeros(N, F, dtype=torch.float64, device='cuda').index_add_(0, src, norm[:, None] * x.double()[dst])
     assert rel(yt, ref) <= 1e-6
     assert torch.equal(y, gcn._spmm(g.fwd, x, g.nnz_cap))
+
+
+@pytest.mark.parametrize('F', [256, 30])
+def test_hub_rows_chunked_entry_point_vs_single_workgroup_entry_point(F):
+    """ppk_spmm_csr_ws (long rows cut into 1024-entry chunks over the whole grid, partials added in chunk order)
+    against ppk_spmm_csr (one workgroup per long row) through the C-ABI: short rows bit-identical, long rows to
+    fp32 summation accuracy against an fp64 index_add; twice in a row bit-identical (the listing order of the
+    long rows varies from run to run, the sums must not)."""
+    from paccmann_polymer_amd import _C, gcn
+    lib = _C.lib
+    rng = np.random.default_rng(21)
+    N, E = 20000, 400000
+    ei = random_graph(rng, N, E, hubs=3).cuda()
+    g = gcn.CSRGraph(ei, N)
+    rowptr, col, eid, val, _ = g.fwd
+    x = torch.randn(N, F, device='cuda')
+    old = torch.empty(N, F, device='cuda')
+    _C.check(lib.ppk_spmm_csr(_C.p(rowptr), _C.p(col), _C.p(val), N, g.nnz_cap, _C.p(x), F, F, _C.p(old), F, _C.stream()))
+    wsb = lib.ppk_spmm_csr_workspace_bytes(N, g.nnz_cap, F)
+    ws = torch.empty(wsb, dtype=torch.uint8, device='cuda')
+    outs = []
+    for _ in range(2):
+        new = torch.full((N, F), float('nan'), device='cuda')
+        _C.check(lib.ppk_spmm_csr_ws(_C.p(rowptr), _C.p(col), _C.p(val), N, g.nnz_cap, _C.p(x), F, F, _C.p(new), F, _C.p(ws), wsb, _C.stream()))
+        outs.append(new)
+    assert torch.equal(outs[0], outs[1])
+    deg = (rowptr[1:] - rowptr[:-1]).long()
+    short = deg <= 1024
+    assert int((~short).sum()) == 3
+    assert torch.equal(outs[0][short], old[short])
+    nnz = int(rowptr[-1])
+    rows = torch.repeat_interleave(torch.arange(N, device='cuda'), deg)
+    ref = torch.zeros(N, F, dtype=torch.float64, device='cuda').index_add_(0, rows, val[:nnz].double()[:, None] * x.double()[col[:nnz].long()])
+    assert rel(outs[0], ref) <= 1e-6 and rel(old, ref) <= 1e-6
+    assert lib.ppk_spmm_csr_ws(_C.p(rowptr), _C.p(col), _C.p(val), N, g.nnz_cap, _C.p(x), F, F, _C.p(new), F, _C.p(ws), 16, _C.stream()) == -3

@@ -76,16 +76,29 @@ def relation_graph(rng, n_nodes, m):
     return np.stack([key // n_nodes, key % n_nodes]).astype(np.int64)
 
 
-def config3(small):
+def config3(small, kind='molecules'):
+    """kind: 'molecules' (blocks of 20..60 atoms: neighbours sit within a few KB of each other — cache friendly),
+    'random' (the same number of bonds between uniformly random endpoints: every gathered row is a cache miss),
+    'hubs' (random endpoints with a third of the directed edges pointing at 3 nodes: K7's long-row path)."""
     from paccmann_polymer_amd import gcn
     rng = np.random.default_rng(0)
     N = 240_000 if small else 2_400_000
     F = 256
     bonds = molecule_batch(rng, N)
-    ei = torch.tensor(np.concatenate([bonds, bonds[::-1]], axis=1)).cuda()          # symmetrised: directed edges
+    if kind != 'molecules':
+        nb = bonds.shape[1]
+        a, b = rng.integers(0, N, size=nb), rng.integers(0, N, size=nb)
+        keep = a != b
+        bonds = np.stack([a[keep], b[keep]]).astype(np.int64)
+    if kind == 'hubs':
+        ei_np = np.concatenate([bonds, bonds[::-1]], axis=1)
+        ei_np[1, : ei_np.shape[1] // 3] = rng.integers(0, 3, size=ei_np.shape[1] // 3)
+        ei = torch.tensor(ei_np).cuda()
+    else:
+        ei = torch.tensor(np.concatenate([bonds, bonds[::-1]], axis=1)).cuda()      # symmetrised: directed edges
     E = int(ei.shape[1])
     x = torch.randn(N, F, device='cuda')
-    wl = f'configs[2]: GCN message passing, N={N} nodes, E={E} directed edges (+N self loops), F={F}'
+    wl = f'configs[2]: GCN message passing, {kind} graph, N={N} nodes, E={E} directed edges (+N self loops), F={F}'
     t_build = timeit(lambda: gcn.CSRGraph(ei, N), iters=3, warm=1)
     line('K6 csr_build (forward + reverse CSR, host wrapper)', wl, t_build, 2 * 40.0 * (E + N))
     g = gcn.CSRGraph(ei, N)
@@ -93,6 +106,8 @@ def config3(small):
     by = nnz * (4 * F + 12) + N * (4 * F + 8)
     line('K7 k_spmm forward (A_hat x)', wl, timeit(lambda: gcn._spmm(g.fwd, x, g.nnz_cap)), by)
     line('K7 k_spmm backward (A_hat^T dout, reverse CSR)', wl, timeit(lambda: gcn._spmm(g.rev, x, g.nnz_cap)), by)
+    if kind != 'molecules':
+        return
     conv = gcn.GCNConv(F, 512).cuda()
     with torch.no_grad():
         t_conv = timeit(lambda: conv(x, g), iters=5)
@@ -178,8 +193,15 @@ def dense(small):
 if __name__ == '__main__':
     ap = argparse.ArgumentParser()
     ap.add_argument('--small', action='store_true')
+    ap.add_argument('--only', default='all', help='dense | spmm | spmm_random | spmm_hubs | sparse | all')
     args = ap.parse_args()
-    if not os.environ.get("PPK_BENCH_GRAPH_ONLY3"):
+    if args.only in ('all', 'dense'):
         dense(args.small)
-    config3(args.small)
-    config4(args.small)
+    if args.only in ('all', 'spmm'):
+        config3(args.small)
+    if args.only in ('all', 'spmm_random'):
+        config3(args.small, 'random')
+    if args.only in ('all', 'spmm_hubs'):
+        config3(args.small, 'hubs')
+    if args.only in ('all', 'sparse'):
+        config4(args.small)

@@ -71,6 +71,25 @@ class SparseRelationGraph:
             self._up = (up, row[up].contiguous())
         return self._up
 
+    def halo_plan(self, world: int):
+        """plan[r][q]: sorted global ids of the rows owned by rank q (node_ranges) that the anchors of rank r
+        (anchor_ranges) touch: the anchors themselves and every neighbour in their CSR rows.  Cached per world size."""
+        cache = self.__dict__.setdefault('_halo_plans', {})
+        if world not in cache:
+            astarts = self.anchor_ranges(world)
+            starts, _ = node_ranges(self.N, world)
+            bounds = torch.tensor(starts, dtype=torch.int64, device=self.col.device)
+            plan = []
+            for r in range(world):
+                a0, a1 = int(astarts[r]), int(astarts[r + 1])
+                j0, j1 = int(self.rowptr[a0]), int(self.rowptr[a1])
+                need = torch.unique(torch.cat([self.col[j0:j1].to(torch.int64),
+                                               torch.arange(a0, a1, dtype=torch.int64, device=self.col.device)]))
+                cut = torch.searchsorted(need, bounds).tolist()
+                plan.append([need[cut[q]:cut[q + 1]] for q in range(world)])
+            cache[world] = plan
+        return cache[world]
+
     def anchor_ranges(self, world: int, deg2_weight: float = 4.0):
         """Work-balanced contiguous ANCHOR ranges for `world` ranks (independent of which rank owns a node's
         latent: z is all-gathered, any rank can evaluate any anchor).  Relation graphs are power-law: with
@@ -173,6 +192,59 @@ class _AllGatherRows(torch.autograd.Function):
         return out, None, None
 
 
+def _exchange_rows(send, recv_rows, width, group):
+    """Variable-size all-to-all of row blocks: send[q] goes to rank q, returns what every rank sent here
+    (recv_rows[q] rows from rank q).  RCCL: one all_to_all on device tensors; gloo (CPU-side tests, no alltoall
+    there): point-to-point through host buffers."""
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    dev, dt = send[rank].device, send[rank].dtype
+    if dist.get_backend(group) == 'nccl':
+        outs = [torch.empty(recv_rows[q], width, dtype=dt, device=dev) for q in range(world)]
+        dist.all_to_all(outs, [t.contiguous() for t in send], group=group)
+        return outs
+    bufs = [torch.empty(recv_rows[q], width, dtype=dt) for q in range(world)]
+    ops = []
+    for q in range(world):
+        if q == rank:
+            continue
+        ops.append(dist.P2POp(dist.isend, send[q].detach().cpu().contiguous(), q, group))
+        ops.append(dist.P2POp(dist.irecv, bufs[q], q, group))
+    if ops:
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
+    return [send[rank].detach().clone() if q == rank else bufs[q].to(dev) for q in range(world)]
+
+
+class _HaloRows(torch.autograd.Function):
+    """z_full [N, Z] holding ONLY the rows this rank's anchors touch (the anchors and their neighbours), fetched from
+    their owners; every other row stays zero and is never read.  Backward: the partial gradient of exactly those
+    rows travels back to the owners, which add the contributions in rank order (fixed order)."""
+
+    @staticmethod
+    def forward(ctx, z_local, graph, group):
+        world, rank = dist.get_world_size(group), dist.get_rank(group)
+        plan = graph.halo_plan(world)
+        starts, _ = node_ranges(graph.N, world)
+        send_idx = [plan[q][rank] - starts[rank] for q in range(world)]          # my rows that rank q needs
+        recv_idx = plan[rank]                                                      # rows I need, by owner
+        zl = z_local.contiguous()
+        got = _exchange_rows([zl[i] for i in send_idx], [int(i.numel()) for i in recv_idx], zl.shape[1], group)
+        z_full = zl.new_zeros(graph.N, zl.shape[1])
+        for q in range(world):
+            z_full[recv_idx[q]] = got[q]
+        ctx.send_idx, ctx.recv_idx, ctx.group, ctx.n_local = send_idx, recv_idx, group, zl.shape[0]
+        return z_full
+
+    @staticmethod
+    def backward(ctx, dz_full):
+        world = dist.get_world_size(ctx.group)
+        got = _exchange_rows([dz_full[i] for i in ctx.recv_idx], [int(i.numel()) for i in ctx.send_idx], dz_full.shape[1], ctx.group)
+        out = dz_full.new_zeros(ctx.n_local, dz_full.shape[1])
+        for q in range(world):                                                     # unique indices per q, ranks in order
+            out.index_add_(0, ctx.send_idx[q], got[q])
+        return out, None, None
+
+
 def node_ranges(num_nodes: int, world: int):
     """Contiguous node ownership: rank r owns [starts[r], starts[r+1])."""
     base, rem = divmod(num_nodes, world)
@@ -183,12 +255,13 @@ def node_ranges(num_nodes: int, world: int):
     return starts, counts
 
 
-def graph_loss_sparse(z, graph: SparseRelationGraph, shard: bool = False, group=None):
+def graph_loss_sparse(z, graph: SparseRelationGraph, shard: bool = False, group=None, exchange: str = 'halo'):
     """loss = (1 / max_e D_e) * sum over anchors of the column / row raster terms
     restricted to `graph`'s edges.  `shard=False`: `z` is the full [N, Z] latent
     matrix.  `shard=True` (torch.distributed initialised): `z` holds this rank's
     contiguous node range; returns the GLOBAL loss on every rank and back-propagates
-    the complete local gradient."""
+    the complete local gradient.  `exchange`: 'halo' moves only the latent rows a rank's anchors touch (and their
+    gradient rows back), 'allgather' the whole matrix (all-gather / reduce-scatter); same result."""
     if not shard:
         if z.shape[0] != graph.N:
             raise ValueError()
@@ -197,6 +270,11 @@ def graph_loss_sparse(z, graph: SparseRelationGraph, shard: bool = False, group=
     starts, counts = node_ranges(graph.N, world)
     if z.shape[0] != counts[rank]:
         raise ValueError()
-    z_full = _AllGatherRows.apply(z.to(torch.float32), counts, group)
+    if exchange == 'halo':
+        z_full = _HaloRows.apply(z.to(torch.float32), graph, group)
+    elif exchange == 'allgather':
+        z_full = _AllGatherRows.apply(z.to(torch.float32), counts, group)
+    else:
+        raise ValueError(exchange)
     astarts = graph.anchor_ranges(world)
     return _SparseGraphLoss.apply(z_full, graph, astarts[rank], astarts[rank + 1], group)

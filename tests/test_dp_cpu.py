@@ -120,3 +120,53 @@ def test_shard_bundles_is_a_partition():
     for world in (1, 2, 3, 8):
         got = sorted(i for r in range(world) for i in shard_bundles(37, r, world))
         assert got == list(range(37))
+
+
+def _halo_rank_main(rank, world, q, port):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from paccmann_polymer_amd.graph_loss_sparse import _HaloRows, node_ranges
+
+        class FakeGraph:                                   # only what _HaloRows reads: N and the exchange plan
+            N = 9
+
+            def halo_plan(self, w):
+                t = lambda *a: torch.tensor(a, dtype=torch.int64)   # noqa: E731
+                # owners: rank 0 rows 0..4, rank 1 rows 5..8.  rank 0 touches {0, 1, 4 | 5, 8}, rank 1 {1, 3 | 5, 6, 7, 8}
+                return [[t(0, 1, 4), t(5, 8)], [t(1, 3), t(5, 6, 7, 8)]]
+        g = FakeGraph()
+        starts, counts = node_ranges(g.N, world)
+        z_all = torch.arange(g.N * 2, dtype=torch.float32).reshape(g.N, 2) + 1.0
+        zl = z_all[starts[rank]:starts[rank + 1]].clone().requires_grad_(True)
+        zf = _HaloRows.apply(zl, g, None)
+        touched = torch.cat(g.halo_plan(world)[rank])
+        want = torch.zeros_like(z_all)
+        want[touched] = z_all[touched]
+        ok = torch.equal(zf.detach(), want)
+        # every rank back-propagates (rank + 1) into the rows it touched: owners receive the sum over the touching ranks
+        (zf * (rank + 1.0)).sum().backward()
+        expect = torch.zeros(g.N, 2)
+        for r in range(world):
+            expect[torch.cat(g.halo_plan(world)[r])] += r + 1.0
+        ok = ok and torch.equal(zl.grad, expect[starts[rank]:starts[rank + 1]])
+        q.put((rank, bool(ok)))
+    finally:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def test_halo_exchange_two_ranks_gloo():
+    """Rows travel to the ranks whose anchors touch them and gradient rows travel back to the owners, summed in
+    rank order (graph_loss_sparse._HaloRows; the point-to-point path gloo takes, no GPU)."""
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_halo_rank_main, args=(r, 2, q, 29653)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(30)
+        assert p.exitcode == 0
+    assert all(ok for _, ok in res), res

@@ -142,6 +142,13 @@ def config4(small):
         for r in range(8):
             a0, a1 = starts[r], starts[r + 1]
             cases.append((f'rank {r} of 8, {name}', (a0, a1), float(rp[a1] - rp[a0]) / float(2 * E)))
+    plan = graph.halo_plan(8)
+    halo = [sum(int(plan[r][q].numel()) for q in range(8) if q != r) for r in range(8)]
+    print(json.dumps(dict(kernel='K5 exchange, 8 ranks: latent rows a rank receives before its kernels (and sends gradient rows for afterwards)',
+                          workload=f'configs[3]: N={N} nodes, E={E} undirected power-law edges, Z={Z}',
+                          halo_rows_per_rank=halo, allgather_rows_per_rank=N - N // 8,
+                          halo_over_allgather=round(float(np.mean(halo)) / (N - N // 8), 4),
+                          note='row counts from the exchange plan; the exchange itself is NOT timed: no multi-GPU node was available')), flush=True)
     worst = {}
     for share, (a0, a1), frac in cases:
         wl = f'configs[3]: sparse graph-reg loss, N={N} nodes, E={E} undirected edges, Z={Z}, {share}'

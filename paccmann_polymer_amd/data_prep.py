@@ -62,6 +62,9 @@ def packed_sequential_data_preparation(
         return inp, decoder, target
 
     if input_keep == 1 and len(input_batch) > 0 and all(torch.is_tensor(x) and x.dim() == 1 and x.numel() > 0 for x in input_batch):
+        # (_packed_preparation_device does the index arithmetic on the GPU instead: measured 3.2-4.6 ms against 4.0 ms at
+        # batch 2048 and 0.21 against 0.15 ms at 21 sequences — the time is the Python list -> one flat tensor part that
+        # both share, so the host path stays the default)
         return _packed_preparation_vectorised(input_batch, device)
     batch = [_process_sample(s) for s in input_batch]
     out = []
@@ -105,6 +108,47 @@ def _packed_preparation_vectorised(input_batch, device):
     note_token_range(dec_d, lo, hi)
     note_token_range(tgt_d, min(lo, 0), hi)
     si, ui = sorted_idx.to(device), unsorted_idx.to(device)
+    return [PackedSequence(data_d, batch_sizes, si, ui), PackedSequence(dec_d, batch_sizes, si, ui),
+            PackedSequence(tgt_d, batch_sizes, si, ui)]
+
+
+def _packed_preparation_device(input_batch, device):
+    """The same three PackedSequences with the packing done ON THE DEVICE: the host keeps only
+    what PackedSequence needs there — the lengths, their sort (the `torch.sort(lengths, descending=True)` of
+    `pack_sequence(enforce_sorted=False)`, so ties order identically) and `batch_sizes` (a histogram of the lengths) —
+    and ships the concatenated token stream once; packed position p -> (timestep t, sorted row i) -> source index is
+    index arithmetic on the device (a searchsorted over the step offsets and two gathers), no [T, B] mask anywhere.
+    Integers bit-equal to the host path (tests/test_data_prep.py)."""
+    lengths = torch.tensor([int(x.numel()) for x in input_batch], dtype=torch.int64)
+    flat = torch.cat([x.reshape(-1) for x in input_batch]).long()
+    lo, hi = int(flat.min()), int(flat.max())                      # host-side range for the token check (no device sync later)
+    starts = torch.cumsum(lengths, 0) - lengths
+    sorted_len, sorted_idx = torch.sort(lengths, descending=True)
+    unsorted_idx = torch.empty_like(sorted_idx)
+    unsorted_idx[sorted_idx] = torch.arange(sorted_idx.numel(), dtype=torch.int64)
+    T = int(sorted_len[0])
+    # batch_sizes[t] = number of sequences longer than t
+    hist = torch.bincount(lengths, minlength=T + 1)
+    batch_sizes = (lengths.numel() - torch.cumsum(hist, 0))[:T]
+    off = torch.cumsum(batch_sizes, 0) - batch_sizes               # first packed position of step t
+    n_tok = int(lengths.sum())
+    flat_d = flat.to(device, non_blocking=True)
+    off_d = off.to(device, non_blocking=True)
+    si = sorted_idx.to(device, non_blocking=True)
+    start_sorted_d = starts[sorted_idx].to(device, non_blocking=True)
+    len_sorted_d = sorted_len.to(device, non_blocking=True)
+    p = torch.arange(n_tok, dtype=torch.int64, device=device)
+    t_idx = torch.searchsorted(off_d, p, right=True) - 1
+    i_idx = p - off_d[t_idx]
+    src = start_sorted_d[i_idx] + t_idx
+    data_d = flat_d[src]
+    last = t_idx + 1 >= len_sorted_d[i_idx]
+    tgt_d = torch.where(last, torch.zeros_like(data_d), flat_d[torch.where(last, src, src + 1)])
+    dec_d = data_d.clone()
+    note_token_range(data_d, lo, hi)
+    note_token_range(dec_d, lo, hi)
+    note_token_range(tgt_d, min(lo, 0), hi)
+    ui = unsorted_idx.to(device, non_blocking=True)
     return [PackedSequence(data_d, batch_sizes, si, ui), PackedSequence(dec_d, batch_sizes, si, ui),
             PackedSequence(tgt_d, batch_sizes, si, ui)]
 

@@ -110,3 +110,20 @@ def test_packed_preparation_vectorised_path_is_bit_exact(B, lo, hi, seed):
         assert torch.equal(got.unsorted_indices, want.unsorted_indices)
     dec.data[0] = -7                                   # the decoder stream is its own storage (reference: input.clone())
     assert enc.data[0] != -7
+
+
+@pytest.mark.parametrize('B,lo,hi,seed', [(1, 1, 1, 0), (300, 1, 6, 1), (2048, 20, 100, 2), (17, 5, 5, 3), (21, 1, 40, 4)])
+def test_packed_preparation_device_arithmetic_is_bit_exact(B, lo, hi, seed):
+    """The packer that runs on the device (position -> (step, row) -> source index by searchsorted + gathers): the
+    same function evaluated on the CPU device against pack_sequence; the GPU run is in tests/test_gpu_stackgru.py."""
+    rng = np.random.default_rng(seed)
+    seqs = [torch.tensor(rng.integers(2, 60, size=int(rng.integers(lo, hi + 1)))) for _ in range(B)]
+    enc, dec, tgt = DP._packed_preparation_device(seqs, 'cpu')
+    ref = pack_sequence(seqs, enforce_sorted=False)
+    ref_t = pack_sequence([torch.cat([s[1:], torch.tensor([0])]) for s in seqs], enforce_sorted=False)
+    for got, want in ((enc, ref), (dec, ref), (tgt, ref_t)):
+        assert torch.equal(got.data, want.data)
+        assert torch.equal(got.batch_sizes, want.batch_sizes) and got.batch_sizes.device.type == 'cpu'
+        assert torch.equal(got.sorted_indices, want.sorted_indices)
+        assert torch.equal(got.unsorted_indices, want.unsorted_indices)
+    assert DP.known_token_range(enc.data) == (int(ref.data.min()), int(ref.data.max()))

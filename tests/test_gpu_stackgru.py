@@ -256,3 +256,34 @@ def test_stack_beyond_the_lds_image_is_refused():
     seqs = make_batch(np.random.default_rng(0), 3, params['vocab_size'], 3, 6)
     with pytest.raises((RuntimeError, ValueError)):
         enc.encoder_train_step(pack_sequence(seqs, enforce_sorted=False))
+
+
+def test_device_packer_equals_pack_sequence_and_times():
+    """The packer whose index arithmetic runs on the device (data_prep._packed_preparation_device) and the default host
+    packer: integers bit-equal to pack_sequence at batch 2048 and at a reference-size bundle; prints the time of both
+    (no gain from the device: both spend their time turning the Python list into one tensor)."""
+    import time
+    from torch.nn.utils.rnn import pack_sequence
+    from paccmann_polymer_amd import data_prep as DP
+    for B, lo, hi in ((2048, 20, 100), (21, 3, 60)):
+        rng = np.random.default_rng(B)
+        seqs = [torch.tensor(rng.integers(2, 60, size=int(rng.integers(lo, hi + 1)))) for _ in range(B)]
+        ref = pack_sequence(seqs, enforce_sorted=False)
+        ref_t = pack_sequence([torch.cat([s[1:], torch.tensor([0])]) for s in seqs], enforce_sorted=False)
+        for packer in (DP._packed_preparation_device, DP._packed_preparation_vectorised):
+            enc, dec, tgt = packer(seqs, 'cuda')
+            for got, want in ((enc, ref), (dec, ref), (tgt, ref_t)):
+                assert got.data.is_cuda and torch.equal(got.data.cpu(), want.data)
+                assert torch.equal(got.batch_sizes, want.batch_sizes) and got.batch_sizes.device.type == 'cpu'
+                assert torch.equal(got.sorted_indices.cpu(), want.sorted_indices)
+                assert torch.equal(got.unsorted_indices.cpu(), want.unsorted_indices)
+        times = {}
+        for name, fn in (('device', lambda: DP._packed_preparation_device(seqs, 'cuda')), ('host', lambda: DP._packed_preparation_vectorised(seqs, 'cuda'))):
+            fn()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(5):
+                fn()
+            torch.cuda.synchronize()
+            times[name] = (time.perf_counter() - t0) / 5 * 1e3
+        print(f'packing B={B}: device-side {times["device"]:.2f} ms, host-side {times["host"]:.2f} ms per call')

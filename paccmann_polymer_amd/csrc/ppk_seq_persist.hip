@@ -144,26 +144,36 @@ __device__ __noinline__ void heads_partial(HeadsCtx c, f32x4 ho0, f32x4 ho1)
     st4(hs + er * HS_LD + c4, er < c.n0 ? ho0 : f32x4{0.f, 0.f, 0.f, 0.f});
     st4(hs + HS_TILE + er * HS_LD + c4, er < c.n1 ? ho1 : f32x4{0.f, 0.f, 0.f, 0.f});
     __syncthreads();
+    // one 32 x 32 output tile per wave (m-tile s x 32 head columns), K = 32 as 16 MFMAs: the fragments are 4 LDS reads of
+    // 16 bytes (h) and 16 of 4 bytes (weights), against 72 16-byte reads per thread for the same product on the VALU
+    float* out = g_lds + 4096;                        // [tiles][32][EPI_LD]
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), li = lane & 31, hh = lane >> 5;
+    const int nhn = ldcs >> 5;                        // head-column halves (ldcs <= 64)
+    if (wave < 2 * nhn) {
+        const int s = wave / nhn, nh = wave - s * nhn;
+        if ((s ? c.n1 : c.n0) > 0) {                  // wave-uniform
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+            for (int cb = 0; cb < 4; ++cb) {
+                const f32x4 hv = ld4(hs + s * HS_TILE + li * HS_LD + 8 * cb + 4 * hh);
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(hv[k], g_wl[(8 * cb + 4 * hh + k) * ldcs + 32 * nh + li], acc, 0, 0, 0);
+            }
+            tile_to_lds(out + wave * EPI_TILE, acc, li, hh);
+        }
+    }
+    __syncthreads();
     for (int o8 = og * 8; o8 < ldcs; o8 += 64) {
         for (int s = 0; s < 2; ++s) {
             const int n = s ? c.n1 : c.n0;
-            if (n == 0) continue;                     // workgroup-uniform
-            f32x4 p0 = {0.f, 0.f, 0.f, 0.f}, p1 = p0;
-#pragma unroll
-            for (int cb = 0; cb < 8; ++cb) {
-                const f32x4 hv = ld4(hs + s * HS_TILE + er * HS_LD + 4 * cb);
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const float* wp = g_wl + (4 * cb + k) * ldcs + o8;
-                    const f32x4 w0 = ld4(wp), w1 = ld4(wp + 4);
-#pragma unroll
-                    for (int x = 0; x < 4; ++x) { p0[x] = fmaf(hv[k], w0[x], p0[x]); p1[x] = fmaf(hv[k], w1[x], p1[x]); }
-                }
-            }
             if (er < n) {
+                const float* t = out + (s * nhn + (o8 >> 5)) * EPI_TILE + er * EPI_LD + (o8 & 31);
                 const long long off = ((long long)(32 * s + er) * ldcs + o8) * 4;
-                st4_sc1(c.dst, off, p0);
-                st4_sc1(c.dst, off + 16, p1);
+                st4_sc1(c.dst, off, ld4(t));
+                st4_sc1(c.dst, off + 16, ld4(t + 4));
             }
         }
     }

@@ -321,8 +321,10 @@ struct StackCtx {
     const float* hpart_g;        // partials of this group: [ntiles][64][ldcs]
     const float* bcs; const float* Sprev; float* Snew; float* CS; float* XS;     // Sprev / Snew / CS / XS: at this step's first packed row
     int W, DW, ldcs, ks, rb, ntiles, bt, j, r0a, r0b;
+    int* wctr; int* status; int wtarget;      // the group wait for the top layer's heads happens INSIDE: the previous stack rows
+                                              // (this workgroup's own stores of the step before) are requested first
 };
-__device__ __noinline__ void stack_phase(StackCtx c)
+__device__ __noinline__ bool stack_phase(StackCtx c)
 {
     float* lds = g_lds;
     const int W = c.W, DW = c.DW, DW4 = (DW + 3) & ~3, ldcs = c.ldcs, ks = c.ks, tid = threadIdx.x, RB = c.rb;
@@ -339,6 +341,7 @@ __device__ __noinline__ void stack_phase(StackCtx c)
         srow = (long long)r0 + (rho & 31);
         return srow < c.bt;
     };
+    bool waited = false;
     for (int rho0 = c.j; rho0 < 64; rho0 += RB * c.ntiles) {
         bool any = false;
         for (int k = 0; k < RB; ++k) { long long sr; any = any || rowinfo(rho0 + k * c.ntiles, sr); }
@@ -366,6 +369,8 @@ __device__ __noinline__ void stack_phase(StackCtx c)
                     if (on[k] && e < n4) tmp[k][x] = ld4(sp[k] + 4 * e);
                 }
         }
+        if (!waited) { if (!group_wait(c.wctr, c.wtarget, c.status, &g_flag)) return false; waited = true; }
+        TSTAMP(5);
         // heads = partials of the ntiles workgroups added in tile order + bias; sixteen independent 16-byte loads per thread
         for (int e = tid; e < RB * (ldcs >> 2); e += 256) {
             const int k = e / (ldcs >> 2), o = (e - k * (ldcs >> 2)) * 4, rho = rho0 + k * c.ntiles;
@@ -477,11 +482,14 @@ __device__ __noinline__ void stack_phase(StackCtx c)
             if (rowinfo(rho0 + k * c.ntiles, sr)) st4_sc1(c.XS, (sr * ks + o) * 4, ld4(top + k * ks + o));      // handed to the group
         }
     }
+    if (!waited && !group_wait(c.wctr, c.wtarget, c.status, &g_flag)) return false;      // no owned row active: same step order
+    return true;
 }
 
 __device__ __forceinline__ StackCtx stack_ctx(const SeqArgs& a, const int* r0, const int* off, int t, int g, int j)
 {
     StackCtx c;
+    c.wctr = a.ctr + (long long)g * (a.L + 1) + (a.L - 1); c.status = a.status; c.wtarget = a.ntiles * (t + 1);      // + the "step -1" signal
     const long long DW = (long long)a.D * a.W, ot = off[t], op = t > 0 ? off[t - 1] : 0;
     c.hpart_g = a.hpart + (long long)g * a.ntiles * 64 * a.ldcs;
     c.bcs = a.bcs;
@@ -557,8 +565,7 @@ __global__ __launch_bounds__(256, 2) void k_seq_fwd(const SeqArgs a)
         heads_partial(heads_ctx(a, g, j, n0[0], n0[1]), hv[0], hv[1]);
     }
     group_signal(ctr + (a.L - 1));
-    if (!group_wait(ctr + (a.L - 1), a.ntiles, a.status, &g_flag)) return;
-    stack_phase(stack_ctx(a, r0, off, 0, g, j));
+    if (!stack_phase(stack_ctx(a, r0, off, 0, g, j))) return;
     group_signal(ctr + a.L);
     for (int t = 0; t < a.T; ++t) {
         const int bt = a.bs[t];
@@ -577,9 +584,7 @@ __global__ __launch_bounds__(256, 2) void k_seq_fwd(const SeqArgs a)
             if (!ok) return;
         }
         if (t + 1 < a.T && a.bs[t + 1] > r0[0]) {
-            if (!group_wait(ctr + (a.L - 1), a.ntiles * (t + 2), a.status, &g_flag)) return;      // + the "step -1" signal
-            TSTAMP(5);
-            stack_phase(stack_ctx(a, r0, off, t + 1, g, j));
+            if (!stack_phase(stack_ctx(a, r0, off, t + 1, g, j))) return;      // waits for the heads of step t inside
             TSTAMP(6);
             group_signal(ctr + a.L);
             TSTAMP(7);

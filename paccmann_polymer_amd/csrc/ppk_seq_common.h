@@ -54,6 +54,12 @@ __device__ __forceinline__ void group_signal(int* ctr)
     if (threadIdx.x == 0) __hip_atomic_fetch_add(ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 // one lane polls, acquires, then the workgroup barrier; false = timeout / another workgroup gave up
+// cycles / 64 between two polls of a group counter.  Same-box ABBA runs at batch 2048 (tools/ab_bench.sh), k_seq_bwd ms:
+// 1: 20.65, 8: 20.13, 24: 19.56, 64: 19.12, 127: 18.70, 254: 19.16, back-off 8..127: 19.27 — every poll is an agent-scope
+// load on a word that the group's producers are about to add to, and it queues with the neighbour's streaming
+#ifndef PPK_POLL_SLEEP
+#define PPK_POLL_SLEEP 127
+#endif
 __device__ __forceinline__ bool group_wait(int* ctr, int target, int* status, volatile int* flag)
 {
     if (threadIdx.x == 0) {
@@ -61,7 +67,20 @@ __device__ __forceinline__ bool group_wait(int* ctr, int target, int* status, vo
         for (int it = 0; it < SPIN_LIMIT; ++it) {
             if (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target) { ok = 1; break; }
             if ((it & 255) == 255 && __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
-            __builtin_amdgcn_s_sleep(8);
+#if PPK_POLL_SLEEP == 0
+            // back-off: 8, 16, 32, 64, then 127 x 64 cycles between polls (a poll is an agent-scope load that queues with
+            // the co-resident workgroup's streaming)
+            if (it == 0) __builtin_amdgcn_s_sleep(8);
+            else if (it == 1) __builtin_amdgcn_s_sleep(16);
+            else if (it == 2) __builtin_amdgcn_s_sleep(32);
+            else if (it == 3) __builtin_amdgcn_s_sleep(64);
+            else __builtin_amdgcn_s_sleep(127);
+#elif PPK_POLL_SLEEP > 127
+            __builtin_amdgcn_s_sleep(127);
+            __builtin_amdgcn_s_sleep(PPK_POLL_SLEEP - 127);
+#else
+            __builtin_amdgcn_s_sleep(PPK_POLL_SLEEP);
+#endif
         }
         if (!ok) __hip_atomic_store(status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");

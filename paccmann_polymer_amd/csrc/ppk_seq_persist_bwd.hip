@@ -284,7 +284,10 @@ struct StackCtx {
     float* dS;                   // [B, D W] by sorted row
     int W, DW, ldcs, ks, rb, ntiles, bt, j, r0a, r0b;
 };
-__device__ __forceinline__ void stack_bwd(StackCtx c)
+// The first pair's rows of the incoming stack gradient and of the previous stack do not depend on the other
+// workgroups' dXS partials: they are requested by LDS-DMA BEFORE the group wait (wctr / wtarget), which therefore
+// happens in here.
+__device__ __forceinline__ bool stack_bwd(StackCtx c, int* wctr, int wtarget, int* status)
 {
     const int W = c.W, DW = c.DW, DW4 = (DW + 3) & ~3, ldcs = c.ldcs, ks = c.ks, tid = threadIdx.x, RB = c.rb;
     const int lane = tid & 63, wave = tid >> 6;
@@ -305,11 +308,37 @@ __device__ __forceinline__ void stack_bwd(StackCtx c)
         srow = (long long)r0 + (rho & 31);
         return srow < c.bt;
     };
+    bool waited = false;
     for (int rho0 = c.j; rho0 < 64; rho0 += RB * c.ntiles) {
         bool any = false;
         for (int k = 0; k < RB; ++k) { long long s_; any = any || rowinfo(rho0 + k * c.ntiles, s_); }
         if (!any) continue;                           // workgroup-uniform
         __syncthreads();
+        bool pre = false;                             // pair 0 already in dst / spl (without its dXS share)
+        if (!waited) {
+            if (vec && (DW >> 2) <= 4 * 256) {
+                // 1 KB pieces (one wave instruction each), dealt to the four waves; lanes beyond the row stay off
+                const int n4 = DW >> 2;
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    long long srk = 0;
+                    if (!(k < RB && rowinfo(rho0 + k * c.ntiles, srk))) continue;       // workgroup-uniform
+                    for (int pi = wave; pi * 64 < n4; pi += 4) {
+                        const int e = pi * 64 + lane;
+                        if (e < n4) {
+                            __builtin_amdgcn_global_load_lds(c.dS + srk * DW + 4 * e, PPK_LDS_PTR(dst + k * DW4 + pi * 256), 16, 0, 0);
+                            if (c.Sprev) __builtin_amdgcn_global_load_lds(c.Sprev + srk * DW + 4 * e, PPK_LDS_PTR(spl + k * DW4 + pi * 256), 16, 0, 0);
+                            else st4(spl + k * DW4 + 4 * e, f32x4{0.f, 0.f, 0.f, 0.f});
+                        }
+                    }
+                }
+                pre = true;
+            }
+            if (!group_wait(wctr, wtarget, status, &g_flag)) return false;
+            waited = true;
+            wait_vmcnt<0>();                          // this wave's pieces have landed
+            __syncthreads();
+        }
         // dXS rows = partials of the ntiles workgroups added in tile order (sixteen loads in flight); heads of the rows
         for (int e = tid; e < RB * (ks >> 2); e += 256) {
             const int k = e / (ks >> 2), o = (e - k * (ks >> 2)) * 4, rho = rho0 + k * c.ntiles;
@@ -344,7 +373,11 @@ __device__ __forceinline__ void stack_bwd(StackCtx c)
             if (!on[0] && !on[1]) continue;           // workgroup-uniform
             __syncthreads();                          // xr / act written; the previous pair of rows is done with dst / spl
             // the two rows -> LDS, all loads issued together
-            if (vec) {
+            if (kb == 0 && pre) {
+#pragma unroll
+                for (int k = 0; k < 2; ++k)
+                    if (on[k]) for (int e = tid; e < W; e += 256) dst[k * DW4 + e] += xr[k * ks + e];      // the stack top fed layer 0: + dXS
+            } else if (vec) {
                 const int n4 = DW >> 2;
                 for (int e0 = 0; e0 < n4; e0 += 4 * 256) {
                     f32x4 tg[2][4], ts[2][4];
@@ -450,6 +483,8 @@ __device__ __forceinline__ void stack_bwd(StackCtx c)
             if (rowinfo(rho0 + k * c.ntiles, s_)) st4_sc1(c.DCS, (s_ * ldcs + o) * 4, ld4(dc + k * ldcs + o));     // handed to the group
         }
     }
+    if (!waited && !group_wait(wctr, wtarget, status, &g_flag)) return false;      // no owned row active: same step order
+    return true;
 }
 
 __device__ __forceinline__ StackCtx stack_ctx(const BwdArgs& a, const int* r0, const int* off, int t, int g, int j)
@@ -563,9 +598,8 @@ __device__ __forceinline__ bool step_bwd(const BwdArgs& a, float* lds, const int
     }
     TSTAMP(4);
     group_signal(ctr + 0);
-    if (!group_wait(ctr + 0, a.ntiles * (k + 1), a.status, &g_flag)) return false;
     TSTAMP(5);
-    stack_bwd(stack_ctx(a, r0, off, t, g, j));
+    if (!stack_bwd(stack_ctx(a, r0, off, t, g, j), ctr + 0, a.ntiles * (k + 1), a.status)) return false;     // waits for E_0 inside
     TSTAMP(6);
     group_signal(ctr + L);
     // ---- carry_0 += dgh_0 . W_hh[0]: only this workgroup's next step needs it — it fills the hand-off latency

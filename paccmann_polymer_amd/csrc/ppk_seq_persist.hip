@@ -86,35 +86,42 @@ template <int NA, int NSEL, bool BF>
 __device__ __forceinline__ void kloop(float* lds, const float* s0, const float* s1, const float* s2, const float* s3, const float* s4,
                                       int nk, f32x16 (&acc)[2][4], int wave, int lane)
 {
+    // buffer = the NA A blocks followed by the three B blocks; with one active m-tile the region holds FOUR buffers
+    // (three stages in flight behind the one barrier per stage), with two m-tiles three (two in flight)
     constexpr int PPW = 3 + NA;
+    constexpr int SB = (3 + NA) * 1024;               // floats per buffer
+    constexpr int NB = NA == 1 ? 4 : 3;
+    static_assert(NB * SB <= REGION, "staging fits the shared region");
     const int li = lane & 31, h = lane >> 5;
     const int xo = li * BK + 4 * ((2 * wave + h) ^ ((li >> 1) & 7));
     auto stage = [&](int buf) {
-        float* base = lds + buf * STG_BUF + wave * 256;
+        float* base = lds + buf * SB + wave * 256;
         __builtin_amdgcn_global_load_lds(s0, PPK_LDS_PTR(base), 16, 0, 0); s0 += BK;
         if constexpr (NA == 2) { __builtin_amdgcn_global_load_lds(s1, PPK_LDS_PTR(base + 1024), 16, 0, 0); s1 += BK; }
-        __builtin_amdgcn_global_load_lds(s2, PPK_LDS_PTR(base + 2048), 16, 0, 0); s2 += BK;
-        __builtin_amdgcn_global_load_lds(s3, PPK_LDS_PTR(base + 3072), 16, 0, 0); s3 += BK;
-        __builtin_amdgcn_global_load_lds(s4, PPK_LDS_PTR(base + 4096), 16, 0, 0); s4 += BK;
+        __builtin_amdgcn_global_load_lds(s2, PPK_LDS_PTR(base + NA * 1024), 16, 0, 0); s2 += BK;
+        __builtin_amdgcn_global_load_lds(s3, PPK_LDS_PTR(base + (NA + 1) * 1024), 16, 0, 0); s3 += BK;
+        __builtin_amdgcn_global_load_lds(s4, PPK_LDS_PTR(base + (NA + 2) * 1024), 16, 0, 0); s4 += BK;
     };
     __syncthreads();                                  // the shared region is free (previous epilogue / stack phase done)
-    // (refilling a buffer one stage earlier behind a second barrier — three stages in flight — pays in the backward's
-    // leaner stages, ppk_seq_persist_bwd.hip, but measured slower here: 24 MFMAs per stage already cover the latency)
-    if (nk > 0) stage(0);
-    if (nk > 1) stage(1);
-    int cur = 0, nxt = 2;
+    // (refilling a buffer one stage earlier behind a SECOND barrier pays in the backward's leaner stages,
+    // ppk_seq_persist_bwd.hip, but measured slower here: 16.9 against 15.9 ms in a same-box A/B)
+#pragma unroll
+    for (int p = 0; p < NB - 1; ++p) if (nk > p) stage(p);
+    int cur = 0, nxt = NB - 1;
     for (int it = 0; it < nk; ++it) {
-        if (it + 1 < nk) wait_vmcnt<PPW>(); else wait_vmcnt<0>();
+        const int rem = nk - 1 - it;                  // stages issued after this one
+        if constexpr (NB == 4) { if (rem >= 2) wait_vmcnt<2 * PPW>(); else if (rem == 1) wait_vmcnt<PPW>(); else wait_vmcnt<0>(); }
+        else { if (rem >= 1) wait_vmcnt<PPW>(); else wait_vmcnt<0>(); }
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        if (it + 2 < nk) stage(nxt);
-        nxt = nxt == NBUF - 1 ? 0 : nxt + 1;
-        const float* base = lds + cur * STG_BUF + xo;
+        if (it + NB - 1 < nk) stage(nxt);
+        nxt = nxt == NB - 1 ? 0 : nxt + 1;
+        const float* base = lds + cur * SB + xo;
         Frag<BF> a[NA], b[3];
 #pragma unroll
         for (int s = 0; s < NA; ++s) a[s].set(*(const f32x4*)(base + s * 1024));
 #pragma unroll
-        for (int q = 0; q < 3; ++q) b[q].set(*(const f32x4*)(base + (2 + q) * 1024));
+        for (int q = 0; q < 3; ++q) b[q].set(*(const f32x4*)(base + (NA + q) * 1024));
 #pragma unroll
         for (int st = 0; st < 4; ++st)
 #pragma unroll
@@ -123,7 +130,7 @@ __device__ __forceinline__ void kloop(float* lds, const float* s0, const float* 
                 mma_chunk(acc[s][1], a[s], b[1], st);
                 mma_chunk(acc[s][NSEL], a[s], b[2], st);
             }
-        cur = cur == NBUF - 1 ? 0 : cur + 1;
+        cur = cur == NB - 1 ? 0 : cur + 1;
     }
 }
 

@@ -18,7 +18,8 @@ constexpr int BK = 32;
 constexpr int EPI_LD = 32;                     // floats per transposed accumulator row: a thread reads (row = tid / 8, 4 columns), so
                                                // every 16-lane read group covers 256 contiguous bytes without padding
 constexpr int EPI_TILE = 32 * EPI_LD;
-constexpr int SPIN_LIMIT = 1 << 22;            // polls of ~0.5 us: seconds
+constexpr int SPIN_LIMIT = 1 << 19;            // polls ~6 us apart (PPK_POLL_SLEEP): ~3 s, then the status word is set, every workgroup
+                                               // leaves at its next wait and the kernels write a NaN into their result
 #define PPK_LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
 
 template <int N> __device__ __forceinline__ void wait_vmcnt()

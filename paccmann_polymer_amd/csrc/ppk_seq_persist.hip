@@ -572,7 +572,7 @@ __global__ __launch_bounds__(256, 2) void k_seq_fwd(const SeqArgs a)
         heads_partial(heads_ctx(a, g, j, n0[0], n0[1]), hv[0], hv[1]);
     }
     group_signal(ctr + (a.L - 1));
-    if (!stack_phase(stack_ctx(a, r0, off, 0, g, j))) return;
+    if (!stack_phase(stack_ctx(a, r0, off, 0, g, j))) { if (threadIdx.x == 0) a.Hs[0] = __builtin_nanf(""); return; }      // a hand-off never arrived (status word set): make it visible in the result
     group_signal(ctr + a.L);
     for (int t = 0; t < a.T; ++t) {
         const int bt = a.bs[t];
@@ -588,10 +588,10 @@ __global__ __launch_bounds__(256, 2) void k_seq_fwd(const SeqArgs a)
         for (int l = 0; l < a.L; ++l) {
             const bool ok = st.n[1] > 0 ? cell<2, BF>(a, lds, &g_flag, r0, st, t, l, g, j, wave, lane, tacc, tlast)
                                         : cell<1, BF>(a, lds, &g_flag, r0, st, t, l, g, j, wave, lane, tacc, tlast);
-            if (!ok) return;
+            if (!ok) { if (threadIdx.x == 0) a.Hs[0] = __builtin_nanf(""); return; }      // a hand-off never arrived (status word set): make it visible in the result
         }
         if (t + 1 < a.T && a.bs[t + 1] > r0[0]) {
-            if (!stack_phase(stack_ctx(a, r0, off, t + 1, g, j))) return;      // waits for the heads of step t inside
+            if (!stack_phase(stack_ctx(a, r0, off, t + 1, g, j))) { if (threadIdx.x == 0) a.Hs[0] = __builtin_nanf(""); return; }      // a hand-off never arrived (status word set): make it visible in the result
             TSTAMP(6);
             group_signal(ctr + a.L);
             TSTAMP(7);

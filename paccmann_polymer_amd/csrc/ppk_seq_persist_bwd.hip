@@ -679,12 +679,12 @@ __global__ __launch_bounds__(256, 2) void k_seq_bwd(const BwdArgs a)
         }
         const bool ok = st.n[1] > 0 ? step_bwd<2, BF>(a, lds, r0, off, st, t, k, g, j, wave, lane)
                                     : step_bwd<1, BF>(a, lds, r0, off, st, t, k, g, j, wave, lane);
-        if (!ok) return;
+        if (!ok) { if (threadIdx.x == 0) a.carry[0] = __builtin_nanf(""); return; }      // a hand-off never arrived (status word set): make it visible in the gradient
     }
     // the stack of step 0 read the INITIAL hidden state of the top layer: dh0[L-1] += DCS_0 . [W_c ; W_s]
     if (Tg > 0) {
         int* ctr = a.ctr + (long long)g * (a.L + 1);
-        if (!group_wait(ctr + a.L, a.ntiles * Tg, a.status, &g_flag)) return;
+        if (!group_wait(ctr + a.L, a.ntiles * Tg, a.status, &g_flag)) { if (threadIdx.x == 0) a.carry[0] = __builtin_nanf(""); return; }      // a hand-off never arrived (status word set): make it visible in the gradient
         const int i = 8 * wave + (lane >> 3), li = lane & 31, hh = lane >> 5, er = tid >> 3, c4 = (tid & 7) * 4, u = 32 * j + c4;
         f32x16 accD[2], accC[2];
         zero_acc(accD);

@@ -42,7 +42,7 @@ int gemm_ntF(const NtProblem* ps, int count, hipStream_t stream);    // 128 x (3
 //      row-block groups synchronised only among their own workgroups ----
 // auto mode (ppk_seq_persist_mode(-1)): the persistent launch is taken from this batch size up.  Measured on MI355X
 // (tools/persist_threshold.py, H 512, L 2, len 20..100; training step, per-step launches vs persistent, ms):
-// B 16: 15.8 / 20.2, 64: 16.9 / 29.0, 256: 19.6 / 27.8, 512: 25.3 / 30.0, 1024: 35.7 / 34.8, 2048: 53.3 / 49.9
+// B 16: 16.0 / 21.6, 64: 17.2 / 29.9, 256: 19.7 / 28.7, 512: 28.4 / 30.3, 1024: 35.4 / 33.8, 2048: 53.3 / 47.2
 constexpr int SEQP_AUTO_MIN_B = 1024;
 constexpr int SEQP_MAXT = 512, SEQP_MAXL = 8;
 int mfma_mode(int mode = -1);        // 0 fp32 operands (default), 1 bf16 operands; other values only query

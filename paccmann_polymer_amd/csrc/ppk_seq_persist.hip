@@ -16,20 +16,24 @@
 //   acc_nh       += W_hn[l] h_l(t-1)              so this runs while the group's slower members finish
 //   acc_r, acc_z, acc_ni += W_ih[l] x_l(t)      "part B": x_0 = stack top (K = ks), x_l = h_{l-1}(t)
 // with fp32 MFMA 32x32x2.  K tiles of 32 are staged for the whole workgroup by LDS-DMA
-// (global_load_lds, source-side XOR swizzle, 3 buffers, one s_barrier per K tile); inside a K tile the
+// (global_load_lds, source-side XOR swizzle, one s_barrier per K tile; 3 buffers / two stages in flight with two
+// active m-tiles, 4 buffers / three in flight with one); inside a K tile the
 // four waves split K (wave w takes the 8-wide chunk w) and each wave accumulates ALL active m-tiles x
 // gates: when the short m-tile of a group has ended, every wave still has work (half of it) instead
 // of two waves idling.  The four partial tiles are summed in wave order in the epilogue (fixed
-// order: bitwise reproducible).  After the top layer, each workgroup updates the stack rows it owns
-// (stack heads on the VALU from a transposed [H, 3+W] weight copy, push/pop/no-op blend) and
-// publishes the new stack tops.
+// order: bitwise reproducible).  After the top layer every workgroup multiplies ITS 32 units of the new
+// hidden tile with its slice of the transposed head weights (kept in LDS; one 32 x 32 MFMA tile per
+// wave) and hands that partial to the row's static owner (row rho belongs to n-tile rho mod ntiles); the
+// owner adds the partials in tile order, applies softmax / tanh and the push / pop / no-op blend to its
+// stack rows (requested before it waits for the partials) and publishes the new stack tops.
 //
 // Cross-workgroup hand-offs (hidden tiles, stack tops) follow MI355X_MICROARCH.md's valid forms:
 // producer = write-through (sc1) 16-byte stores, every wave drains vmcnt, workgroup barrier, ONE
 // agent-scope counter add; consumer = ONE lane polls (relaxed, agent), agent acquire (buffer_inv sc1),
 // vmcnt(0), workgroup barrier, then plain loads / LDS-DMA.  Every hand-off line is written once
 // before any reader touches it and by exactly one workgroup (128-byte row segments).  Polls are
-// bounded: on a timeout the kernel raises a status word and every workgroup leaves.
+// 127 x 64 cycles apart (ppk_seq_common.h) and bounded: on a timeout (~3 s) the kernel raises a status
+// word, every workgroup leaves at its next wait and a NaN is written into the result.
 #include "ppk_common.h"
 #include "ppk_kernels.h"
 #include "ppk_seq_common.h"
@@ -41,11 +45,8 @@ namespace {
 using namespace ppk_seq;
 
 constexpr int MAXT = ppk::SEQP_MAXT, MAXL = ppk::SEQP_MAXL;
-constexpr int STG_BUF = 5 * 1024;              // floats per staging buffer: A slot 0, A slot 1, B r, B z, B n (32 x 32 each)
-constexpr int NBUF = 3;
 constexpr int REGION = 4 * 4 * EPI_TILE;       // floats: 4 waves x 4 accumulators, transposed (also staging / stack scratch)
 constexpr int WL_MAX = 32 * 64;                // floats: this workgroup's slice of the transposed head weights (ldcs <= 64)
-static_assert(NBUF * STG_BUF <= REGION, "staging fits the shared region");
 
 struct SeqArgs {
     int T, B, H, L, W, D, V, ks, ldcs, ntiles, G, MT, g0, g1, tpx, xt, rb, pair, hgrid;

@@ -13,11 +13,14 @@
 //                                                                                        the dr, dz two thirds of K)
 //   layer 0: dXS = dgi_0 . W_ih0[:, E:E+W] as per-n-tile partials (K split over the workgroups that hold the operands),
 //            added by the owner of the stack row, then the stack-update backward of the rows a workgroup owns
-//            (one wave per row: three dot products over the D x W row by wave shuffles), DCS_t handed to the group;
+//            (two rows at a time in LDS, all threads on them, the three dot products per row as block reductions; the first
+//            pair of rows is fetched by LDS-DMA before the wait for the partials), DCS_t handed to the group;
 //            accC of layer 0 (carry_0 += dgh_0 . W_hh[0]) runs AFTER that hand-off: nothing waits for it but this
 //            workgroup's own next step, so it fills the group's synchronisation latency.
-// MFMA fp32 32x32x2, K tiles of 32 staged for the workgroup by LDS-DMA (4 buffers, one s_barrier per K tile), the four
-// waves split each K tile (wave w takes chunk w) and accumulate all active m-tiles; partial tiles summed in wave order.
+// MFMA fp32 32x32x2 (bf16 operands under ppk_mfma_mode(1)), two products or two K tiles per stage, staged for the workgroup by
+// LDS-DMA: 3 buffers, three stages in flight, a buffer refilled behind a second s_barrier once every wave holds its
+// fragments; the four waves split each K tile (wave w takes chunk w) and accumulate all active m-tiles; partial tiles summed
+// in wave order.
 // Hand-offs (dgi / dgh rows, DCS rows, dXS partials) as in the forward: write-through stores + counter, poll + acquire.
 #include "ppk_common.h"
 #include "ppk_kernels.h"

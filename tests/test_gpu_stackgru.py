@@ -287,3 +287,43 @@ def test_device_packer_equals_pack_sequence_and_times():
             torch.cuda.synchronize()
             times[name] = (time.perf_counter() - t0) / 5 * 1e3
         print(f'packing B={B}: device-side {times["device"]:.2f} ms, host-side {times["host"]:.2f} ms per call')
+
+
+def test_persistent_launch_in_several_machine_fulls_equals_per_step_launches():
+    """More groups than fit the device at once (FULL architecture: 16 workgroups per group, 32 groups resident; batch
+    2304 = 36 groups): the persistent path launches a machine-full of groups at a time.  Same loss and gradients as
+    the per-step launch schedule on the same batch (short sequences keep it cheap)."""
+    from paccmann_polymer_amd import _C
+    from paccmann_polymer_amd import stack_gru_vae as M
+    lib = _C.lib
+    rng = np.random.default_rng(77)
+    seqs = make_batch(rng, 2304, FULL['vocab_size'], 3, 9)
+    enc, dec, tgt = prep(seqs)
+
+    def dev(p):
+        from torch.nn.utils.rnn import PackedSequence
+        return PackedSequence(p.data.cuda(), p.batch_sizes, p.sorted_indices.cuda(), p.unsorted_indices.cuda())
+    enc, dec, tgt = dev(enc), dev(dec), dev(tgt)
+    eps = torch.randn(len(seqs), FULL['latent_dim'], device='cuda', generator=torch.Generator('cuda').manual_seed(5))
+    out = {}
+    try:
+        for mode in (0, 1):
+            assert lib.ppk_seq_persist_mode(mode) == mode
+            torch.manual_seed(3)
+            vae = M.TeacherVAE(M.StackGRUEncoder(FULL), M.StackGRUDecoder(FULL)).cuda()
+            vae.train()
+            vae.encoder._update_batch_size(len(seqs))
+            vae.decoder._update_batch_size(len(seqs))
+            mu, logvar = vae.encode(enc)
+            z = vae.reparameterize(mu, logvar, eps).unsqueeze(0)
+            loss = vae.decode(z, dec, tgt)
+            loss.backward()
+            torch.cuda.synchronize()
+            out[mode] = (float(loss.detach()), {n: p.grad.detach().clone() for n, p in vae.named_parameters() if p.grad is not None})
+    finally:
+        lib.ppk_seq_persist_mode(-1)
+    (l0, g0), (l1, g1) = out[0], out[1]
+    assert abs(l0 - l1) <= 1e-5 * abs(l0), (l0, l1)
+    for n in g0:
+        scale = float(g0[n].abs().max())
+        assert float((g0[n] - g1[n]).abs().max()) <= 2e-4 * max(scale, 1e-12), n

@@ -156,10 +156,18 @@ int ppk_gemm_tn_colsum_f32(int64_t M, int64_t N, int64_t K, const float* A, int6
  * limit < -1 only queries; returns the value in force. */
 int64_t ppk_nt_small_grid_limit(int64_t limit);
 
-/* Tuning / test hook of K1: the sequence entry points run the whole time loop as ONE persistent launch (row-block
- * groups synchronised among their own workgroups only) whenever the shape allows; mode 0 switches that off
- * (one launch per layer-step, the round-1 schedule), -1 / 1 switch it back on, any other value only queries.
- * Process-global like ppk_nt_small_grid_limit.  Returns the value in force. */
+/* Launch schedule of K1 (ppk_stackgru_seq_fwd / _bwd).  Two schedules compute the same step: the whole time loop as ONE
+ * persistent launch per pass (row-block groups synchronised among their own workgroups only), or one launch per
+ * layer-step.  mode:
+ *   -1  auto (default; PPK_SEQ_PERSIST in the environment): persistent from batch 1024 up (where it is faster on
+ *       MI355X, tools/persist_threshold.py), per-step launches below;
+ *    0  never persistent;
+ *    1  persistent at ANY batch, wherever the shape is supported (H % 32 == 0, ks / ldcs at their minimal paddings
+ *       roundup32(W) / roundup32(3 + W), one group's workgroups resident together on the current device); an
+ *       unsupported shape takes the per-step launches.
+ * Any other value only queries.  Process-global like ppk_nt_small_grid_limit.  Returns the value in force.
+ * A persistent launch whose workgroups lose a hand-off (bounded wait, ~2 s; another process holding the GPU can cause
+ * it) fills every output of the call with NaN: the entry point still returns PPK_OK (it never synchronises). */
 int ppk_seq_persist_mode(int mode);
 
 /* Arithmetic of the MFMA products of K1's persistent sequence kernels (BASELINE.json configs[4], "bf16-MFMA variant
@@ -169,7 +177,8 @@ int ppk_seq_persist_mode(int mode);
  *      everything outside the products (gate math, stack, hand-offs, memory) stays fp32.  The long-K weight-gradient
  *      GEMM behind ppk_gemm_tn_colsum_f32 / ppk_gemm_f32 (TN, k_tn128) follows the same mode.  Tolerance vs mode 0 on the
  *      training step: loss 2e-3 relative, gradients 5e-2 of the largest entry per tensor (tests/test_gpu_bf16.py).
- * In K1 it takes effect only where the persistent kernels run (ppk_seq_persist_mode != 0 and a supported shape).  Any other
+ * In K1 it takes effect only where the persistent kernels run: in auto mode (ppk_seq_persist_mode -1) that is from
+ * batch 1024 up — below it mode 1 changes nothing in K1 unless ppk_seq_persist_mode(1) forces the persistent launch.  Any other
  * value only queries.  Process-global.  Returns the value in force. */
 int ppk_mfma_mode(int mode);
 
@@ -192,6 +201,12 @@ int ppk_mfma_mode(int mode);
  * its epilogue (plus the recurrent products needed by the next step).
  * Saved activations (caller-allocated, consumed by the backward):
  *   XS [NT, ks] (stack top), Hs / HP [L, NT, H], gates [L, NT, 4H], S [NT, D, W], CS [NT, ldcs].
+ * Training-mode dropout of nn.GRU(dropout = p) (the reference trains with gru_vae.train(), reactions_vae.py:44, on
+ * params whose `dropout` key comes from the pretrained JSON, paccmann_encoder.py:41-45): torch applies it to the
+ * output of every layer but the last, on the way to the next layer only (the recurrent path keeps the undropped
+ * state).  drop [L-1, NT, H] holds the factor of every (layer, packed row, unit): 0 or 1 / (1 - p)
+ * (ppk_dropout_factors draws them; a test injects its own); Hdrop [L-1, NT, H] receives Hs * drop, the input
+ * of the layer above (saved: it is the operand of dW_ih[l >= 1]).  drop == NULL: no dropout, Hdrop unused.
  */
 size_t ppk_stackgru_seq_fwd_workspace_bytes(int64_t B, int64_t H, int64_t L, int64_t W);
 int ppk_stackgru_seq_fwd(int64_t T, const int64_t* batch_sizes_host, int64_t B, int64_t NT,
@@ -201,22 +216,29 @@ int ppk_stackgru_seq_fwd(int64_t T, const int64_t* batch_sizes_host, int64_t B, 
                          const float* const* b_ih, const float* const* b_hh,
                          const float* wcs, const float* bcs, const float* h0, const float* S0,
                          float* XS, float* Hs, float* HP, float* gates, float* S,
-                         float* CS, int64_t ldcs, void* workspace, size_t ws_bytes, ppk_stream_t stream);
+                         float* CS, int64_t ldcs, const float* drop, float* Hdrop,
+                         void* workspace, size_t ws_bytes, ppk_stream_t stream);
+/* drop factors for ppk_stackgru_seq_fwd / _bwd: out[l, row, u] = keep ? 1 / (1 - p) : 0 with keep drawn by Philox4x32-10
+ * keyed by (seed, l, row, u / 4): a pure function of its index, independent of launch geometry and schedule.
+ * Units >= H_valid (zero padding of the hidden size) get factor 0.  0 <= p < 1. */
+int ppk_dropout_factors(uint64_t seed, float p, int64_t layers, int64_t NT, int64_t H, int64_t H_valid, float* out,
+                        ppk_stream_t stream);
 /* dHtop [NT, H] = gradient at the top layer's output of every step.  Outputs:
  * dXS [NT, ks] (gradient of the stack top fed to layer 0), DGI / DGH [L, NT, 3H] (gate
  * pre-activation gradients of the input / hidden side), DCS [NT, ldcs], dh0 [L, B, H].
- * Weight gradients are single GEMMs over these: dW_ih[l>=1] = DGI^T Hs[l-1], dW_ih0[:, E:] = DGI0^T XS,
+ * Weight gradients are single GEMMs over these: dW_ih[l>=1] = DGI^T Hs[l-1] (Hdrop[l-1] under dropout), dW_ih0[:, E:] = DGI0^T XS,
  * dtable = rows of DGI0 summed per token, dW_hh = DGH^T HP, dWcs = DCS^T HP[L-1].
  * The backward takes the weights TRANSPOSED (host arrays of L device pointers:
  * w_ih_t[0] [W, 3H] = stack columns of weight_ih_l0, w_ih_t[l>=1] [H, 3H], w_hh_t[l] [H, 3H];
- * wcs_t [H, ldcs] zero padded) so that the per-step data-gradient GEMMs read k-contiguous operands. */
+ * wcs_t [H, ldcs] zero padded) so that the per-step data-gradient GEMMs read k-contiguous operands.
+ * drop: the factors the forward ran with (NULL: none). */
 size_t ppk_stackgru_seq_bwd_workspace_bytes(int64_t B, int64_t H, int64_t L, int64_t W, int64_t D);
 int ppk_stackgru_seq_bwd(int64_t T, const int64_t* batch_sizes_host, int64_t B, int64_t NT,
                          int64_t H, int64_t L, int64_t W, int64_t D,
                          const float* const* w_ih_t, const float* const* w_hh_t, const float* wcs_t,
                          const float* HP, const float* gates, const float* S, const float* CS, int64_t ldcs,
                          const float* dHtop, float* dXS, int64_t ks, float* DGI, float* DGH, float* DCS,
-                         float* dh0, void* workspace, size_t ws_bytes, ppk_stream_t stream);
+                         float* dh0, const float* drop, void* workspace, size_t ws_bytes, ppk_stream_t stream);
 
 /* ---- row gather / scatter, column sums, embedding gradient ----------------
  * (index_select / index_put / sum(0) / nn.Embedding backward in the reference's
@@ -235,9 +257,16 @@ int ppk_colsum(const float* A, int64_t lda, int64_t rows, int64_t cols, float be
  * Limit: ceil(rows / 512) * cols <= 262144, otherwise PPK_ERR_UNSUP with nothing launched.  Bit-identical to ppk_colsum.
  * All calls on one GPU share that GPU's array: calls that overlap on one GPU (streams, threads) race. */
 int ppk_colsum_noalloc(const float* A, int64_t lda, int64_t rows, int64_t cols, float beta, float* out, ppk_stream_t stream);
-size_t ppk_embedding_bwd_workspace_bytes(int64_t NT, int64_t V, int64_t E);
-int ppk_embedding_bwd(const float* dX, int64_t ldx, const int64_t* tokens, int64_t NT, int64_t V, int64_t E,
-                      int64_t padding_idx, float* dEmb, void* workspace, size_t ws_bytes, ppk_stream_t stream);
+
+/* out[k, :] = sum of the rows r of x with keys[r] == k (k in [0, n_keys)), in a fixed order (ascending r inside 64-row
+ * chunks, a key's chunks ascending): bitwise reproducible, sort-free (stable counting sort on the device).
+ * The embedding-table gradient of K1: autograd's nn.Embedding backward for the reference (paccmann_encoder.py:166,168)
+ * scatters per token with float atomics; here the rows of the layer-0 gate gradients are summed per token id.
+ * n_keys <= 8192; F, ldx, ldo multiples of 4; status [1] (device int) becomes non-zero if a key was out of range
+ * (those rows are skipped). */
+size_t ppk_rowsum_by_key_workspace_bytes(int64_t n_rows, int64_t n_keys, int64_t F);
+int ppk_rowsum_by_key(const int64_t* keys, int64_t n_rows, int64_t n_keys, const float* x, int64_t ldx, int64_t F,
+                      float* out, int64_t ldo, int* status, void* workspace, size_t ws_bytes, ppk_stream_t stream);
 
 /* ---- K2: cross-entropy over packed logits ---------------------------------
  * nn.CrossEntropyLoss(ignore_index=0) of TeacherVAE.decode (paccmann_encoder.py:168):
@@ -287,6 +316,13 @@ size_t ppk_csr_build_workspace_bytes(int64_t N, int64_t E);
 int ppk_csr_build(const int64_t* src, const int64_t* dst, int64_t E, int64_t N, int drop_self_loops, int add_self_loops,
                   int normalize, const float* edge_weight, int64_t* rowptr, int64_t* col, int64_t* eid, float* val,
                   int* status, void* workspace, size_t ws_bytes, ppk_stream_t stream);
+/* The same grouping for a rectangular incidence: dst in [0, N) is the CSR row, src in [0, N_src) indexes another table.
+ * Used by the embedding-table gradient of K1 (rows of the packed batch grouped by token: the one-hot product that
+ * autograd's nn.Embedding backward performs for the reference, paccmann_encoder.py:166,168, as a segmented reduction in
+ * a fixed order).  Self loops and normalisation need N_src == N. */
+int ppk_csr_build_rect(const int64_t* src, const int64_t* dst, int64_t E, int64_t N, int64_t N_src, int drop_self_loops,
+                       int add_self_loops, int normalize, const float* edge_weight, int64_t* rowptr, int64_t* col, int64_t* eid,
+                       float* val, int* status, void* workspace, size_t ws_bytes, ppk_stream_t stream);
 /* ---- K7: out[i, :] = sum_{j in row i} val[j] * x[col[j], :] --------------------
  * One wavefront per row, fixed order, no atomics (GCNConv.propagate's gather +
  * scatter_add).  The backward is the same call on the CSR of the reversed edges. */

@@ -63,6 +63,20 @@ class StackGRURef(nn.Module):
         s = torch.zeros(batch, self.stack_depth, self.stack_width, dtype=dtype, device=device)
         return h, s
 
+    # upstream plumbing read by the reference's in-tree callers (latent_space_map_fns.py:284,289)
+    def _update_batch_size(self, batch_size):
+        self.batch_size = int(batch_size)
+
+    @property
+    def init_stack(self):
+        w = self.embedding.weight
+        return self.init_state(getattr(self, 'batch_size', 1), w.dtype, w.device)[1]
+
+    @property
+    def init_hidden(self):
+        w = self.embedding.weight
+        return self.init_state(getattr(self, 'batch_size', 1), w.dtype, w.device)[0]
+
     def stack_augmentation(self, input_val, prev_stack, controls):
         # input_val [B, W], prev_stack [B, D, W], controls [B, 3] = (push, pop, no-op)
         B = prev_stack.shape[0]

@@ -50,18 +50,19 @@ SIGNATURES = {
     'ppk_stackgru_seq_fwd_workspace_bytes': (c_sz, [c_i64, c_i64, c_i64, c_i64]),
     'ppk_stackgru_seq_fwd': (c_int, [c_i64, ptr, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64,
                                      ptr, ptr, ptr, c_i64, ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr,
-                                     ptr, ptr, ptr, ptr, ptr, ptr, c_i64, ptr, c_sz, ptr]),
+                                     ptr, ptr, ptr, ptr, ptr, ptr, c_i64, ptr, ptr, ptr, c_sz, ptr]),
+    'ppk_dropout_factors': (c_int, [ctypes.c_uint64, c_f32, c_i64, c_i64, c_i64, c_i64, ptr, ptr]),
     'ppk_stackgru_seq_bwd_workspace_bytes': (c_sz, [c_i64, c_i64, c_i64, c_i64, c_i64]),
     'ppk_stackgru_seq_bwd': (c_int, [c_i64, ptr, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64,
                                      ptr, ptr, ptr, ptr, ptr, ptr, ptr, c_i64,
-                                     ptr, ptr, c_i64, ptr, ptr, ptr, ptr, ptr, c_sz, ptr]),
+                                     ptr, ptr, c_i64, ptr, ptr, ptr, ptr, ptr, ptr, c_sz, ptr]),
     'ppk_gather_rows': (c_int, [ptr, c_i64, c_i64, ptr, c_i64, c_i64, ptr, c_i64, ptr]),
     'ppk_scatter_rows': (c_int, [ptr, c_i64, ptr, c_i64, c_i64, ptr, c_i64, c_i64, ptr]),
+    'ppk_rowsum_by_key_workspace_bytes': (c_sz, [c_i64, c_i64, c_i64]),
+    'ppk_rowsum_by_key': (c_int, [ptr, c_i64, c_i64, ptr, c_i64, c_i64, ptr, c_i64, ptr, ptr, c_sz, ptr]),
     'ppk_colsum_workspace_bytes': (c_sz, [c_i64, c_i64]),
     'ppk_colsum': (c_int, [ptr, c_i64, c_i64, c_i64, c_f32, ptr, ptr, c_sz, ptr]),
     'ppk_colsum_noalloc': (c_int, [ptr, c_i64, c_i64, c_i64, c_f32, ptr, ptr]),
-    'ppk_embedding_bwd_workspace_bytes': (c_sz, [c_i64, c_i64, c_i64]),
-    'ppk_embedding_bwd': (c_int, [ptr, c_i64, ptr, c_i64, c_i64, c_i64, c_i64, ptr, ptr, c_sz, ptr]),
     'ppk_ce_workspace_bytes': (c_sz, [c_i64]),
     'ppk_ce_fwd': (c_int, [ptr, c_i64, ptr, c_i64, c_i64, c_i64, ptr, ptr, c_sz, ptr]),
     'ppk_ce_bwd': (c_int, [ptr, c_i64, ptr, c_i64, c_i64, c_i64, ptr, ptr, c_i64, ptr, c_sz, ptr]),
@@ -71,6 +72,7 @@ SIGNATURES = {
     'ppk_adam_step': (c_int, [ptr, ptr, ptr, ptr, c_i64, c_f32, c_f32, c_f32, c_f32, c_f32, c_i64, ptr]),
     'ppk_csr_build_workspace_bytes': (c_sz, [c_i64, c_i64]),
     'ppk_csr_build': (c_int, [ptr, ptr, c_i64, c_i64, c_int, c_int, c_int, ptr, ptr, ptr, ptr, ptr, ptr, ptr, c_sz, ptr]),
+    'ppk_csr_build_rect': (c_int, [ptr, ptr, c_i64, c_i64, c_i64, c_int, c_int, c_int, ptr, ptr, ptr, ptr, ptr, ptr, ptr, c_sz, ptr]),
     'ppk_spmm_csr': (c_int, [ptr, ptr, ptr, c_i64, c_i64, ptr, c_i64, c_i64, ptr, c_i64, ptr]),
     'ppk_spmm_csr_workspace_bytes': (c_sz, [c_i64, c_i64, c_i64]),
     'ppk_spmm_csr_ws': (c_int, [ptr, ptr, ptr, c_i64, c_i64, ptr, c_i64, c_i64, ptr, c_i64, ptr, c_sz, ptr]),

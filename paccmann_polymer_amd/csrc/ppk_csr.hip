@@ -43,11 +43,11 @@ inline unsigned grid_for(long long work, unsigned cap = 8192)
 
 // cnt[target] += 1 for every non-self-loop edge (integer atomics: order-independent result)
 __global__ __launch_bounds__(256) void k_count(const int64_t* __restrict__ src, const int64_t* __restrict__ dst, long long E,
-                                               long long N, int drop_self_loops, int* __restrict__ cnt, int* __restrict__ bad)
+                                               long long N, long long NS, int drop_self_loops, int* __restrict__ cnt, int* __restrict__ bad)
 {
     for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < E; e += (long long)gridDim.x * 256) {
         const long long s = src[e], d = dst[e];
-        if (s < 0 || s >= N || d < 0 || d >= N) { atomicOr(bad, 1); continue; }
+        if (s < 0 || s >= NS || d < 0 || d >= N) { atomicOr(bad, 1); continue; }
         if (drop_self_loops && s == d) continue;
         atomicAdd(&cnt[d], 1);
     }
@@ -124,7 +124,7 @@ __global__ __launch_bounds__(256) void k_scan_add(long long* __restrict__ rowptr
 
 // fill: arbitrary position inside the row; the self loop gets edge id E + i (sorts last)
 __global__ __launch_bounds__(256) void k_fill(const int64_t* __restrict__ src, const int64_t* __restrict__ dst, long long E,
-                                              long long N, int drop_self_loops, int add_self_loops,
+                                              long long N, long long NS, int drop_self_loops, int add_self_loops,
                                               const long long* __restrict__ rowptr, int* __restrict__ cursor,
                                               long long* __restrict__ eid)
 {
@@ -134,7 +134,7 @@ __global__ __launch_bounds__(256) void k_fill(const int64_t* __restrict__ src, c
         if (e < E) {
             const long long s = src[e];
             d = dst[e];
-            if (s < 0 || s >= N || d < 0 || d >= N) continue;
+            if (s < 0 || s >= NS || d < 0 || d >= N) continue;
             if (drop_self_loops && s == d) continue;
         } else {
             d = e - E;
@@ -513,11 +513,26 @@ size_t ppk_csr_build_workspace_bytes(int64_t N, int64_t E)
 //   normalize : val = deg^-1/2[src] * w * deg^-1/2[dst], deg = weighted in-degree incl. self loop (unit weights only)
 //   edge_weight : optional [E]; must be NULL when normalize != 0
 // status[0] (device int) is set non-zero when an edge endpoint is out of range (such edges are skipped).
+int ppk_csr_build_rect(const int64_t* src, const int64_t* dst, int64_t E, int64_t N, int64_t N_src, int drop_self_loops,
+                       int add_self_loops, int normalize, const float* edge_weight, int64_t* rowptr, int64_t* col, int64_t* eid,
+                       float* val, int* status, void* workspace, size_t ws_bytes, hipStream_t stream);
 int ppk_csr_build(const int64_t* src, const int64_t* dst, int64_t E, int64_t N, int drop_self_loops, int add_self_loops,
                   int normalize, const float* edge_weight, int64_t* rowptr, int64_t* col, int64_t* eid, float* val,
                   int* status, void* workspace, size_t ws_bytes, hipStream_t stream)
 {
-    if (N < 1 || E < 0) PPK_FAIL(PPK_ERR_SHAPE, "csr_build: N < 1 or E < 0");
+    return ppk_csr_build_rect(src, dst, E, N, N, drop_self_loops, add_self_loops, normalize, edge_weight, rowptr, col, eid, val,
+                              status, workspace, ws_bytes, stream);
+}
+
+// The same grouping for a RECTANGULAR incidence: dst in [0, N) names the CSR row, src in [0, N_src) the gathered row of
+// another table (the embedding-table gradient groups the NT packed rows of a batch by their token, N = V).  Self loops
+// and the symmetric normalisation only exist for square graphs (N_src == N).
+int ppk_csr_build_rect(const int64_t* src, const int64_t* dst, int64_t E, int64_t N, int64_t N_src, int drop_self_loops,
+                       int add_self_loops, int normalize, const float* edge_weight, int64_t* rowptr, int64_t* col, int64_t* eid,
+                       float* val, int* status, void* workspace, size_t ws_bytes, hipStream_t stream)
+{
+    if (N < 1 || E < 0 || N_src < 1) PPK_FAIL(PPK_ERR_SHAPE, "csr_build: N < 1 or E < 0");
+    if (N_src != N && (drop_self_loops || add_self_loops || normalize)) PPK_FAIL(PPK_ERR_UNSUP, "csr_build: self loops / normalisation need a square graph");
     if ((E > 0 && (!src || !dst)) || !rowptr || !col || !eid || !val || !status || !workspace) PPK_FAIL(PPK_ERR_NULL, "csr_build: null pointer");
     if (N > 0x7fffffff || E + N > 0x7fffffffLL * 4) PPK_FAIL(PPK_ERR_UNSUP, "csr_build: graph too large");
     if (normalize && edge_weight) PPK_FAIL(PPK_ERR_UNSUP, "csr_build: normalize with edge weights is not implemented");
@@ -529,7 +544,7 @@ int ppk_csr_build(const int64_t* src, const int64_t* dst, int64_t E, int64_t N, 
     PPK_HIP(hipMemsetAsync(w.n_long, 0, 256, stream));
     PPK_HIP(hipMemsetAsync(w.bad, 0, 256, stream));
     if (E > 0) {
-        k_count<<<dim3(grid_for(E)), dim3(256), 0, stream>>>(src, dst, E, N, drop_self_loops, w.cnt, w.bad);
+        k_count<<<dim3(grid_for(E)), dim3(256), 0, stream>>>(src, dst, E, N, N_src, drop_self_loops, w.cnt, w.bad);
         PPK_CHECK_LAUNCH("k_count");
     }
     k_scan_block<<<dim3(nb), dim3(256), 0, stream>>>(w.cnt, add_self_loops ? 1 : 0, N, (long long*)rowptr, w.block_sums);
@@ -538,7 +553,7 @@ int ppk_csr_build(const int64_t* src, const int64_t* dst, int64_t E, int64_t N, 
     PPK_CHECK_LAUNCH("k_scan_sums");
     k_scan_add<<<dim3((unsigned)((N + 1 + 255) / 256)), dim3(256), 0, stream>>>((long long*)rowptr, w.block_sums, w.total, N);
     PPK_CHECK_LAUNCH("k_scan_add");
-    k_fill<<<dim3(grid_for(E + N)), dim3(256), 0, stream>>>(src, dst, E, N, drop_self_loops, add_self_loops,
+    k_fill<<<dim3(grid_for(E + N)), dim3(256), 0, stream>>>(src, dst, E, N, N_src, drop_self_loops, add_self_loops,
                                                             (const long long*)rowptr, w.cursor, (long long*)eid);
     PPK_CHECK_LAUNCH("k_fill");
     k_sort_short<<<dim3(grid_for(N)), dim3(256), 0, stream>>>((const long long*)rowptr, N, (long long*)eid, w.long_rows, w.n_long);

@@ -181,6 +181,7 @@ __device__ __forceinline__ void epi_gru_bwd(const ppk::NtProblem& g, const float
         if (row >= g.M) continue;
         f32x4 a = ldsum<NPART>(t, pstride, rl * EPI_LD + c4);
         if (row >= g.a_rows) a = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (g.drop) a *= ld4(g.drop + (long long)row * H + col);       // the layer above read hnew * drop (problem-uniform branch)
         f32x4 dr, dz, dn, dnr, c;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -285,6 +286,7 @@ __device__ __forceinline__ void epi_gru_fwd(const ppk::NtProblem& g, const float
             hh[k] = (1.0f - zz[k]) * nn[k] + zz[k] * f.hp[p][k];
         }
         st4(g.hnew + (long long)row * H + u, hh);
+        if (g.drop) st4(g.hdrop + (long long)row * H + u, hh * ld4(g.drop + (long long)row * H + u));      // problem-uniform branch
         st4(g.hp_out + (long long)row * H + u, f.hp[p]);
         float* gt = g.gates_out + (long long)row * 4 * H + u;
         st4(gt, rr); st4(gt + H, zz); st4(gt + 2 * H, nn); st4(gt + 3 * H, f.hn[p]);
@@ -887,6 +889,7 @@ int gemm_ntF(const NtProblem* ps, int count, hipStream_t stream)
             if (p.ldc < p.N) PPK_FAIL(PPK_ERR_SHAPE, "gemm_ntF: ldc < N");
         } else if (p.epi == NT_GRU_FWD) {
             if (!p.gh || !p.hprev || !p.hnew || !p.hp_out || !p.gates_out) PPK_FAIL(PPK_ERR_NULL, "gemm_ntF: null GRU-forward operand");
+            if (p.drop && !p.hdrop) PPK_FAIL(PPK_ERR_NULL, "gemm_ntF: dropout mask without an output for the masked hidden state");
             if (p.table && !p.tok) PPK_FAIL(PPK_ERR_NULL, "gemm_ntF: table without tokens");
             if (p.table && p.V < 1) PPK_FAIL(PPK_ERR_SHAPE, "gemm_ntF: table without its row count");
         } else {

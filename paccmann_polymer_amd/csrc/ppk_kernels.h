@@ -30,6 +30,9 @@ struct NtProblem {
     const float* gh; const float* hprev; const int64_t* tok; const float* table;
     int V;                       // rows of `table`: token ids are clamped to [0, V) in the kernel (the host validates them)
     float* hnew; float* hp_out; float* gates_out;          // [M,H], [M,H], [M,4H] = r, z, n, gh_n
+    // inter-layer dropout of nn.GRU(dropout = p) in training mode (NULL: none).  drop [M,H] holds 0 or 1 / (1 - p):
+    //   NT_GRU_FWD: hdrop = hnew * drop is what the layer above reads;  NT_GRU_BWD: dh = acc * drop + carry (+ ext)
+    const float* drop; float* hdrop;
     // NT_GRU_BWD: dh = acc + carry (+ ext) ; writes dgi, dgh [M,3H] and carry = dh * z
     float* carry; const float* ext; const float* gates_in; const float* hp_in; float* dgi; float* dgh;
 };
@@ -54,7 +57,14 @@ int seq_fwd_persist(int64_t T, const int64_t* bs, int64_t B, int64_t NT, int64_t
                     const float* const* w_ih, const float* const* w_hh, const float* const* b_ih, const float* const* b_hh,
                     const float* wcs, const float* bcs, const float* h0, const float* S0,
                     float* XS, float* Hs, float* HP, float* gates, float* S, float* CS, int64_t ldcs,
-                    void* ws, size_t ws_bytes, hipStream_t stream);
+                    const float* drop, float* Hdrop, void* ws, size_t ws_bytes, hipStream_t stream);
+
+// shared host helpers of the two persistent kernels (ppk_seq_persist.hip)
+int seq_poison(const int* status, float* const* ptrs, const long long* counts, int n, hipStream_t stream);
+int seq_capacity(const void* kernel, int slot);          // slot: 0 / 1 forward fp32 / bf16, 2 / 3 backward
+int seq_groups_per_launch(int capacity, int ntiles, int xt, int tpx);
+void seq_placement(int ntiles, int& xt, int& tpx);
+double seq_row_share(const int* bs, int T, int G, int MT, int pair, int g0, int g1);
 
 bool seq_bwd_persist_ok(int64_t T, int64_t B, int64_t NT, int64_t H, int64_t L, int64_t W, int64_t D, int64_t ks, int64_t ldcs);
 size_t seq_bwd_persist_ws_bytes(int64_t B, int64_t H, int64_t L, int64_t W, int64_t D);
@@ -62,7 +72,7 @@ int seq_bwd_persist(int64_t T, const int64_t* bs, int64_t B, int64_t NT, int64_t
                     const float* const* w_ih_t, const float* const* w_hh_t, const float* wcs_t,
                     const float* HP, const float* gates, const float* S, const float* CS, int64_t ldcs,
                     const float* dHtop, float* dXS, int64_t ks, float* DGI, float* DGH, float* DCS, float* dh0,
-                    void* ws, size_t ws_bytes, hipStream_t stream);
+                    const float* drop, void* ws, size_t ws_bytes, hipStream_t stream);
 
 // ---- opt-in per-kernel timing (HIP events on the launch stream) -------------
 // Off by default; bench.py switches it on for ONE extra step after the timed

@@ -1,10 +1,12 @@
 // Small fused kernels around the GRU core: row gather / scatter, deterministic
-// column sums, embedding gradient, logits cross-entropy (K2), reparameterise +
+// column sums, per-key row sums (embedding-table gradient), logits cross-entropy (K2), reparameterise +
 // KL (K3), flat Adam.  Every reduction has a fixed order (no float atomics).
 #include "ppk_common.h"
 #include <mutex>
 
 namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // Scratch of ppk_colsum_noalloc: the per-chunk partial column sums that ppk_colsum keeps in its caller-provided
 // workspace.  Every GPU the library runs on holds its own copy of this array until the process ends.  In host code
@@ -91,31 +93,144 @@ __global__ __launch_bounds__(256) void k_colsum_final(const float* __restrict__ 
     }
 }
 
-// ---- embedding gradient: dEmb[v, :] = sum_{rows with tok == v} dX[row, 0:E] ----
-constexpr int EB_CHUNK = 2048;
-__global__ __launch_bounds__(128) void k_embbwd_part(const float* __restrict__ dX, long long ldx, const int64_t* __restrict__ tok,
-                                                     long long NT, int E, float* __restrict__ part)
+// ---- rows of a table summed per key, in ascending row order (the embedding-table gradient of K1) ----------------
+// out[k, :] = sum over the rows r with key[r] == k of x[r, :], added in ascending r inside fixed 64-row chunks and
+// the chunks of a key in ascending order: one fixed association whatever the launch geometry (bitwise reproducible).
+// Sort-free: a stable counting sort (per-1024-row-block key histograms in LDS -> per-key prefix over the blocks ->
+// exclusive scan over the keys -> stable rank inside the block) lists every key's rows; a key's list is cut into
+// chunks of RBK_CHUNK rows, one workgroup per (chunk, 1024-column block) gathers its rows with 16-byte loads (eight in
+// flight per lane), and a last pass adds a key's chunk partials in order.
+constexpr int RBK_BLOCK = 1024;       // rows per histogram block
+constexpr int RBK_CHUNK = 64;         // rows per partial sum
+constexpr int RBK_MAX_KEYS = 8192;    // histogram bins kept in LDS
+
+__global__ __launch_bounds__(256) void k_rbk_hist(const int64_t* __restrict__ key, long long n, int nkeys, int* __restrict__ hist, int* __restrict__ bad)
 {
-    // grid (V, nchunks); block covers E columns in strides of 128
-    const int v = blockIdx.x;
-    const long long r0 = (long long)blockIdx.y * EB_CHUNK;
-    const long long r1 = r0 + EB_CHUNK < NT ? r0 + EB_CHUNK : NT;
-    for (int c = threadIdx.x; c < E; c += 128) {
-        float acc = 0.f;
-        for (long long r = r0; r < r1; ++r)
-            if (tok[r] == v) acc += dX[r * ldx + c];
-        part[((long long)blockIdx.y * gridDim.x + v) * E + c] = acc;
+    __shared__ int h[RBK_MAX_KEYS];
+    for (int k = threadIdx.x; k < nkeys; k += 256) h[k] = 0;
+    __syncthreads();
+    const long long r0 = (long long)blockIdx.x * RBK_BLOCK;
+    for (int i = threadIdx.x; i < RBK_BLOCK && r0 + i < n; i += 256) {
+        const long long k = key[r0 + i];
+        if (k < 0 || k >= nkeys) { atomicOr(bad, 1); continue; }
+        atomicAdd(&h[(int)k], 1);                     // integer LDS atomics: order-independent result
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < nkeys; k += 256) hist[(long long)blockIdx.x * nkeys + k] = h[k];
+}
+// per key: exclusive prefix of its block counts (in place), total -> cnt[k]
+__global__ __launch_bounds__(256) void k_rbk_prefix(int* __restrict__ hist, int nblk, int nkeys, int* __restrict__ cnt)
+{
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= nkeys) return;
+    int run = 0;
+    for (int b = 0; b < nblk; ++b) { const int c = hist[(long long)b * nkeys + k]; hist[(long long)b * nkeys + k] = run; run += c; }
+    cnt[k] = run;
+}
+// one workgroup: rowptr = exclusive scan of cnt, chunkptr = exclusive scan of ceil(cnt / RBK_CHUNK)
+__global__ __launch_bounds__(256) void k_rbk_scan(const int* __restrict__ cnt, int nkeys, long long* __restrict__ rowptr, int* __restrict__ chunkptr)
+{
+    __shared__ long long sr[256];
+    __shared__ int sc[256];
+    const int per = (nkeys + 255) / 256, k0 = threadIdx.x * per, k1 = k0 + per < nkeys ? k0 + per : nkeys;
+    long long r = 0;
+    int c = 0;
+    for (int k = k0; k < k1; ++k) { r += cnt[k]; c += (cnt[k] + RBK_CHUNK - 1) / RBK_CHUNK; }
+    sr[threadIdx.x] = r; sc[threadIdx.x] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        long long rr = 0;
+        int cc = 0;
+        for (int t = 0; t < 256; ++t) { const long long a = sr[t]; const int b = sc[t]; sr[t] = rr; sc[t] = cc; rr += a; cc += b; }
+        rowptr[nkeys] = rr; chunkptr[nkeys] = cc;
+    }
+    __syncthreads();
+    r = sr[threadIdx.x]; c = sc[threadIdx.x];
+    for (int k = k0; k < k1; ++k) { rowptr[k] = r; chunkptr[k] = c; r += cnt[k]; c += (cnt[k] + RBK_CHUNK - 1) / RBK_CHUNK; }
+}
+// list[rowptr[k] + (rows of key k in earlier blocks) + (earlier rows of key k in this block)] = row
+__global__ __launch_bounds__(256) void k_rbk_fill(const int64_t* __restrict__ key, long long n, int nkeys, const int* __restrict__ hist,
+                                                  const long long* __restrict__ rowptr, int* __restrict__ list)
+{
+    __shared__ int kk[RBK_BLOCK];
+    const long long r0 = (long long)blockIdx.x * RBK_BLOCK;
+    const int m = (int)(n - r0 < RBK_BLOCK ? n - r0 : RBK_BLOCK);
+    for (int i = threadIdx.x; i < m; i += 256) { const long long k = key[r0 + i]; kk[i] = (k < 0 || k >= nkeys) ? -1 : (int)k; }
+    __syncthreads();
+    for (int i = threadIdx.x; i < m; i += 256) {
+        const int k = kk[i];
+        if (k < 0) continue;
+        int rank = 0;
+        for (int j = 0; j < i; ++j) rank += kk[j] == k;
+        list[rowptr[k] + hist[(long long)blockIdx.x * nkeys + k] + rank] = (int)(r0 + i);
     }
 }
-__global__ __launch_bounds__(256) void k_embbwd_final(const float* __restrict__ part, int nchunks, int V, int E, int padding_idx,
-                                                      float* __restrict__ dEmb)
+// grid (chunk, column block of 1024): part[chunk][cols] = sum of the chunk's rows, ascending
+__global__ __launch_bounds__(256) void k_rbk_partial(const long long* __restrict__ rowptr, const int* __restrict__ chunkptr, int nkeys,
+                                                     const int* __restrict__ list, const float* __restrict__ x, long long ldx, int F,
+                                                     float* __restrict__ part)
 {
-    const long long total = (long long)V * E;
+    const int c = blockIdx.x;
+    if (c >= chunkptr[nkeys]) return;                 // the grid is an upper bound (the chunk count lives on the device)
+    int lo = 0, hi = nkeys;                           // key of this chunk: last k with chunkptr[k] <= c
+    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (chunkptr[mid] <= c) lo = mid; else hi = mid; }
+    const long long b = rowptr[lo] + (long long)(c - chunkptr[lo]) * RBK_CHUNK;
+    const long long e = b + RBK_CHUNK < rowptr[lo + 1] ? b + RBK_CHUNK : rowptr[lo + 1];
+    const int col = blockIdx.y * 1024 + threadIdx.x * 4;
+    if (col >= F) return;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    long long i = b;
+    for (; i + 8 <= e; i += 8) {
+        f32x4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const f32x4*>(x + (long long)list[i + u] * ldx + col);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc += v[u];
+    }
+    for (; i < e; ++i) acc += *reinterpret_cast<const f32x4*>(x + (long long)list[i] * ldx + col);
+    *reinterpret_cast<f32x4*>(part + (long long)c * F + col) = acc;
+}
+// grid (key, column block of 1024): out[key] = sum of its chunk partials, ascending
+__global__ __launch_bounds__(256) void k_rbk_final(const int* __restrict__ chunkptr, const float* __restrict__ part, int F,
+                                                   float* __restrict__ out, long long ldo)
+{
+    const int k = blockIdx.x, col = blockIdx.y * 1024 + threadIdx.x * 4;
+    if (col >= F) return;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int c = chunkptr[k]; c < chunkptr[k + 1]; ++c) acc += *reinterpret_cast<const f32x4*>(part + (long long)c * F + col);
+    *reinterpret_cast<f32x4*>(out + (long long)k * ldo + col) = acc;
+}
+
+// ---- dropout factors: Philox4x32-10, counter = (row lo, row hi, unit / 4, layer), key = seed ----------------------
+__device__ __forceinline__ void philox4x32_10(unsigned (&c)[4], unsigned k0, unsigned k1)
+{
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const unsigned long long p0 = (unsigned long long)0xD2511F53u * c[0], p1 = (unsigned long long)0xCD9E8D57u * c[2];
+        const unsigned n0 = (unsigned)(p1 >> 32) ^ c[1] ^ k0, n1 = (unsigned)p1, n2 = (unsigned)(p0 >> 32) ^ c[3] ^ k1, n3 = (unsigned)p0;
+        c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+}
+__global__ __launch_bounds__(256) void k_dropout_factors(unsigned long long seed, float p, long long layers, long long NT, int H, int Hv,
+                                                         float* __restrict__ out)
+{
+    const int q = H >> 2;                              // groups of four units per row
+    const long long total = layers * NT * q;
+    const float scale = 1.0f / (1.0f - p);
     for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
-        const int v = (int)(e / E);
-        double acc = 0.0;
-        for (int p = 0; p < nchunks; ++p) acc += (double)part[(long long)p * total + e];
-        dEmb[e] = v == padding_idx ? 0.f : (float)acc;
+        const long long lr = e / q;
+        const int u4 = (int)(e - lr * q);
+        const long long l = lr / NT, row = lr - l * NT;
+        unsigned c[4] = {(unsigned)row, (unsigned)(row >> 32), (unsigned)u4, (unsigned)l};
+        philox4x32_10(c, (unsigned)seed, (unsigned)(seed >> 32));
+        f32x4 v;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float uni = (float)(c[k] >> 8) * (1.0f / 16777216.0f);          // [0, 1)
+            v[k] = (4 * u4 + k < Hv && uni >= p) ? scale : 0.f;
+        }
+        *reinterpret_cast<f32x4*>(out + e * 4) = v;
     }
 }
 
@@ -393,25 +508,58 @@ int ppk_colsum_noalloc(const float* A, int64_t lda, int64_t rows, int64_t cols, 
     return PPK_OK;
 }
 
-size_t ppk_embedding_bwd_workspace_bytes(int64_t NT, int64_t V, int64_t E)
+size_t ppk_rowsum_by_key_workspace_bytes(int64_t n_rows, int64_t n_keys, int64_t F)
 {
-    if (NT <= 0 || V <= 0 || E <= 0) return 0;
-    return ppk_align_up(sizeof(float) * (size_t)((NT + EB_CHUNK - 1) / EB_CHUNK) * (size_t)V * (size_t)E, 256);
+    if (n_rows < 1 || n_keys < 1 || F < 1) return 0;
+    const size_t nblk = (size_t)((n_rows + RBK_BLOCK - 1) / RBK_BLOCK), chunks = (size_t)(n_rows / RBK_CHUNK + n_keys);
+    return ppk_align_up(sizeof(int) * nblk * (size_t)n_keys, 256) + ppk_align_up(sizeof(int) * (size_t)n_keys, 256)
+           + ppk_align_up(sizeof(long long) * (size_t)(n_keys + 1), 256) + ppk_align_up(sizeof(int) * (size_t)(n_keys + 1), 256)
+           + ppk_align_up(sizeof(int) * (size_t)n_rows, 256) + ppk_align_up(sizeof(float) * chunks * (size_t)F, 256) + 256;
 }
 
-// dEmb [V, E] (overwritten); row padding_idx is zero (nn.Embedding(padding_idx=...)); pass -1 for none
-int ppk_embedding_bwd(const float* dX, int64_t ldx, const int64_t* tokens, int64_t NT, int64_t V, int64_t E,
-                      int64_t padding_idx, float* dEmb, void* workspace, size_t ws_bytes, hipStream_t stream)
+int ppk_rowsum_by_key(const int64_t* keys, int64_t n_rows, int64_t n_keys, const float* x, int64_t ldx, int64_t F,
+                      float* out, int64_t ldo, int* status, void* workspace, size_t ws_bytes, hipStream_t stream)
 {
-    if (!dX || !tokens || !dEmb || !workspace) PPK_FAIL(PPK_ERR_NULL, "embedding_bwd: null pointer");
-    if (NT < 1 || V < 1 || E < 1 || ldx < E) PPK_FAIL(PPK_ERR_SHAPE, "embedding_bwd: bad sizes");
-    if (ws_bytes < ppk_embedding_bwd_workspace_bytes(NT, V, E)) PPK_FAIL(PPK_ERR_WS, "embedding_bwd: workspace too small");
-    const int nchunks = (int)((NT + EB_CHUNK - 1) / EB_CHUNK);
-    if (nchunks > 65535) PPK_FAIL(PPK_ERR_UNSUP, "embedding_bwd: too many rows");
-    k_embbwd_part<<<dim3((unsigned)V, (unsigned)nchunks), dim3(128), 0, stream>>>(dX, ldx, tokens, NT, (int)E, (float*)workspace);
-    PPK_CHECK_LAUNCH("k_embbwd_part");
-    k_embbwd_final<<<dim3(grid_for(V * E)), dim3(256), 0, stream>>>((const float*)workspace, nchunks, (int)V, (int)E, (int)padding_idx, dEmb);
-    PPK_CHECK_LAUNCH("k_embbwd_final");
+    if (!keys || !x || !out || !status || !workspace) PPK_FAIL(PPK_ERR_NULL, "rowsum_by_key: null pointer");
+    if (n_rows < 1 || n_keys < 1 || F < 1 || ldx < F || ldo < F) PPK_FAIL(PPK_ERR_SHAPE, "rowsum_by_key: bad sizes");
+    if (n_keys > RBK_MAX_KEYS || n_rows > 0x7fffffff) PPK_FAIL(PPK_ERR_UNSUP, "rowsum_by_key: more than %d keys or 2^31 rows", RBK_MAX_KEYS);
+    if ((F & 3) || (ldx & 3) || (ldo & 3) || ((uintptr_t)x & 15) || ((uintptr_t)out & 15)) PPK_FAIL(PPK_ERR_ALIGN, "rowsum_by_key: F, ldx, ldo must be multiples of 4 and the tables 16-byte aligned");
+    if (ws_bytes < ppk_rowsum_by_key_workspace_bytes(n_rows, n_keys, F)) PPK_FAIL(PPK_ERR_WS, "rowsum_by_key: workspace too small");
+    const int nblk = (int)((n_rows + RBK_BLOCK - 1) / RBK_BLOCK), nk = (int)n_keys;
+    const long long chunks = n_rows / RBK_CHUNK + n_keys;
+    char* cur = (char*)workspace;
+    int* hist = (int*)ppk_carve(cur, sizeof(int) * (size_t)nblk * (size_t)nk);
+    int* cnt = (int*)ppk_carve(cur, sizeof(int) * (size_t)nk);
+    long long* rowptr = (long long*)ppk_carve(cur, sizeof(long long) * (size_t)(nk + 1));
+    int* chunkptr = (int*)ppk_carve(cur, sizeof(int) * (size_t)(nk + 1));
+    int* list = (int*)ppk_carve(cur, sizeof(int) * (size_t)n_rows);
+    float* part = (float*)ppk_carve(cur, sizeof(float) * (size_t)chunks * (size_t)F);
+    int* bad = (int*)ppk_carve(cur, 256);
+    PPK_HIP(hipMemsetAsync(bad, 0, 256, stream));
+    k_rbk_hist<<<dim3(nblk), dim3(256), 0, stream>>>(keys, n_rows, nk, hist, bad);
+    PPK_CHECK_LAUNCH("k_rbk_hist");
+    k_rbk_prefix<<<dim3((nk + 255) / 256), dim3(256), 0, stream>>>(hist, nblk, nk, cnt);
+    PPK_CHECK_LAUNCH("k_rbk_prefix");
+    k_rbk_scan<<<dim3(1), dim3(256), 0, stream>>>(cnt, nk, rowptr, chunkptr);
+    PPK_CHECK_LAUNCH("k_rbk_scan");
+    k_rbk_fill<<<dim3(nblk), dim3(256), 0, stream>>>(keys, n_rows, nk, hist, rowptr, list);
+    PPK_CHECK_LAUNCH("k_rbk_fill");
+    const unsigned cb = (unsigned)((F + 1023) / 1024);
+    k_rbk_partial<<<dim3((unsigned)chunks, cb), dim3(256), 0, stream>>>(rowptr, chunkptr, nk, list, x, ldx, (int)F, part);
+    PPK_CHECK_LAUNCH("k_rbk_partial");
+    k_rbk_final<<<dim3((unsigned)nk, cb), dim3(256), 0, stream>>>(chunkptr, part, (int)F, out, ldo);
+    PPK_CHECK_LAUNCH("k_rbk_final");
+    PPK_HIP(hipMemcpyAsync(status, bad, sizeof(int), hipMemcpyDeviceToDevice, stream));
+    return PPK_OK;
+}
+
+int ppk_dropout_factors(uint64_t seed, float p, int64_t layers, int64_t NT, int64_t H, int64_t H_valid, float* out, hipStream_t stream)
+{
+    if (!out) PPK_FAIL(PPK_ERR_NULL, "dropout_factors: null pointer");
+    if (layers < 1 || NT < 1 || H < 4 || (H & 3) || H_valid < 1 || H_valid > H || !(p >= 0.f && p < 1.f)) PPK_FAIL(PPK_ERR_SHAPE, "dropout_factors: bad sizes or p outside [0, 1)");
+    if ((uintptr_t)out & 15) PPK_FAIL(PPK_ERR_ALIGN, "dropout_factors: out must be 16-byte aligned");
+    k_dropout_factors<<<dim3(grid_for(layers * NT * (H / 4), 8192)), dim3(256), 0, stream>>>((unsigned long long)seed, p, layers, NT, (int)H, (int)H_valid, out);
+    PPK_CHECK_LAUNCH("k_dropout_factors");
     return PPK_OK;
 }
 

@@ -18,8 +18,12 @@ constexpr int BK = 32;
 constexpr int EPI_LD = 32;                     // floats per transposed accumulator row: a thread reads (row = tid / 8, 4 columns), so
                                                // every 16-lane read group covers 256 contiguous bytes without padding
 constexpr int EPI_TILE = 32 * EPI_LD;
-constexpr int SPIN_LIMIT = 1 << 19;            // polls ~6 us apart (PPK_POLL_SLEEP): ~3 s, then the status word is set, every workgroup
-                                               // leaves at its next wait and the kernels write a NaN into their result
+#ifndef PPK_SPIN_LIMIT
+#define PPK_SPIN_LIMIT (1 << 19)
+#endif
+constexpr int SPIN_LIMIT = PPK_SPIN_LIMIT;     // polls ~3.4 us apart (PPK_POLL_SLEEP): ~2 s, then the status word is set, every workgroup
+                                               // leaves at its next wait and k_seq_poison turns every output of the launch into NaN
+                                               // (libppk_spin.so, built with -DPPK_SPIN_LIMIT=1, forces that path: tests/test_gpu_stackgru.py)
 #define PPK_LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
 
 template <int N> __device__ __forceinline__ void wait_vmcnt()

@@ -56,6 +56,8 @@ struct SeqArgs {
     const float* w_ih[MAXL]; const float* w_hh[MAXL]; const float* b_ih[MAXL]; const float* b_hh[MAXL];
     const float* wcs_t; const float* bcs; const float* h0; const float* S0;
     float* XS; float* Hs; float* HP; float* gates; float* S; float* CS;
+    const float* drop; float* HD;      // inter-layer dropout (training mode of nn.GRU(dropout = p)): factors [L-1, NT, H] (0 or 1 / (1 - p)),
+                                       // HD [L-1, NT, H] = Hs * drop = what the layer above reads; both null without dropout
     float* hpart;
     int* ctr; int* status;
     long long* dbg;
@@ -96,6 +98,9 @@ __device__ __forceinline__ void kloop(float* lds, const float* s0, const float* 
     const int li = lane & 31, h = lane >> 5;
     const int xo = li * BK + 4 * ((2 * wave + h) ^ ((li >> 1) & 7));
     auto stage = [&](int buf) {
+#ifdef PPK_EXP_NODMA
+        return;
+#endif
         float* base = lds + buf * SB + wave * 256;
         __builtin_amdgcn_global_load_lds(s0, PPK_LDS_PTR(base), 16, 0, 0); s0 += BK;
         if constexpr (NA == 2) { __builtin_amdgcn_global_load_lds(s1, PPK_LDS_PTR(base + 1024), 16, 0, 0); s1 += BK; }
@@ -123,6 +128,11 @@ __device__ __forceinline__ void kloop(float* lds, const float* s0, const float* 
         for (int s = 0; s < NA; ++s) a[s].set(*(const f32x4*)(base + s * 1024));
 #pragma unroll
         for (int q = 0; q < 3; ++q) b[q].set(*(const f32x4*)(base + (NA + q) * 1024));
+#ifdef PPK_EXP_NOMMA
+        asm volatile("" :: "v"(a[0].v), "v"(b[0].v), "v"(b[1].v), "v"(b[2].v));
+        if constexpr (NA == 2) asm volatile("" :: "v"(a[NA - 1].v));
+        if (nk < 0)
+#endif
 #pragma unroll
         for (int st = 0; st < 4; ++st)
 #pragma unroll
@@ -248,7 +258,7 @@ __device__ __forceinline__ bool cell(const SeqArgs& a, float* lds, volatile int*
     // part B: W_ih[l] . x_l(t)
     {
         const int K = l == 0 ? a.ks : H;
-        const float* xp = l == 0 ? a.XS : a.Hs + (long long)(l - 1) * a.NT * H;
+        const float* xp = l == 0 ? a.XS : (a.drop ? a.HD : a.Hs) + (long long)(l - 1) * a.NT * H;
         const float* sa[2];
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
@@ -308,6 +318,9 @@ __device__ __forceinline__ bool cell(const SeqArgs& a, float* lds, volatile int*
             }
             const f32x4 hn = v[3];
             st4_sc1(a.Hs + ((long long)l * a.NT + st.base[s]) * H, ((long long)er * H + u) * 4, ho);      // handed to the group
+            if (a.drop && l < a.L - 1)                   // launch-uniform branch: the layer above reads the dropped-out copy
+                st4_sc1(a.HD + ((long long)l * a.NT + st.base[s]) * H, ((long long)er * H + u) * 4,
+                        ho * ld4(a.drop + ((long long)l * a.NT + row) * H + u));
             st4(a.HP + ((long long)l * a.NT + row) * H + u, hp);
             float* gt = a.gates + ((long long)l * a.NT + row) * 4 * H + u;
             st4(gt, rr); st4(gt + H, zz); st4(gt + 2 * H, nn); st4(gt + 3 * H, hn);
@@ -573,7 +586,7 @@ __global__ __launch_bounds__(256, 2) void k_seq_fwd(const SeqArgs a)
         heads_partial(heads_ctx(a, g, j, n0[0], n0[1]), hv[0], hv[1]);
     }
     group_signal(ctr + (a.L - 1));
-    if (!stack_phase(stack_ctx(a, r0, off, 0, g, j))) { if (threadIdx.x == 0) a.Hs[0] = __builtin_nanf(""); return; }      // a hand-off never arrived (status word set): make it visible in the result
+    if (!stack_phase(stack_ctx(a, r0, off, 0, g, j))) return;      // a hand-off never arrived (status word set; k_seq_poison makes it visible in every output)
     group_signal(ctr + a.L);
     for (int t = 0; t < a.T; ++t) {
         const int bt = a.bs[t];
@@ -589,10 +602,10 @@ __global__ __launch_bounds__(256, 2) void k_seq_fwd(const SeqArgs a)
         for (int l = 0; l < a.L; ++l) {
             const bool ok = st.n[1] > 0 ? cell<2, BF>(a, lds, &g_flag, r0, st, t, l, g, j, wave, lane, tacc, tlast)
                                         : cell<1, BF>(a, lds, &g_flag, r0, st, t, l, g, j, wave, lane, tacc, tlast);
-            if (!ok) { if (threadIdx.x == 0) a.Hs[0] = __builtin_nanf(""); return; }      // a hand-off never arrived (status word set): make it visible in the result
+            if (!ok) return;      // a hand-off never arrived (status word set; k_seq_poison makes it visible in every output)
         }
         if (t + 1 < a.T && a.bs[t + 1] > r0[0]) {
-            if (!stack_phase(stack_ctx(a, r0, off, t + 1, g, j))) { if (threadIdx.x == 0) a.Hs[0] = __builtin_nanf(""); return; }      // a hand-off never arrived (status word set): make it visible in the result
+            if (!stack_phase(stack_ctx(a, r0, off, t + 1, g, j))) return;      // a hand-off never arrived (status word set; k_seq_poison makes it visible in every output)
             TSTAMP(6);
             group_signal(ctr + a.L);
             TSTAMP(7);
@@ -611,6 +624,18 @@ __global__ __launch_bounds__(256) void k_wcs_transpose(const float* __restrict__
         const int k = (int)(e / ldcs), o = (int)(e - (long long)k * ldcs);
         out[e] = o < nout ? wcs[(long long)o * H + k] : 0.f;
     }
+}
+
+// A hand-off that never arrived (status word set by a timed-out wait): every buffer a caller consumes becomes NaN, so a
+// lost hand-off cannot pass as numbers whatever the caller reads.  Launched after the sequence kernel on its stream;
+// costs one status load per workgroup when nothing went wrong.
+struct PoisonArgs { float* p[6]; long long n[6]; };
+__global__ __launch_bounds__(256) void k_seq_poison(const int* __restrict__ status, PoisonArgs a)
+{
+    if (__hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) return;
+    const float nan = __builtin_nanf("");
+    for (int k = 0; k < 6; ++k)
+        for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < a.n[k]; e += (long long)gridDim.x * 256) a.p[k][e] = nan;
 }
 
 long long* g_dbg = nullptr;      // PPK_SEQ_TIMING builds only
@@ -639,15 +664,82 @@ int seq_persist_mode(int mode)
     return force_mode();
 }
 
+int seq_poison(const int* status, float* const* ptrs, const long long* counts, int n, hipStream_t stream)
+{
+    PoisonArgs a{};
+    for (int k = 0; k < n && k < 6; ++k) { a.p[k] = ptrs[k]; a.n[k] = ptrs[k] ? counts[k] : 0; }
+    k_seq_poison<<<dim3(512), dim3(256), 0, stream>>>(status, a);
+    PPK_CHECK_LAUNCH("k_seq_poison");
+    return PPK_OK;
+}
+
+// Workgroups of a sequence kernel that are resident together on the CURRENT device: every workgroup of a group must be,
+// so a launch never carries more groups than fit.  Cached per device and per kernel variant (fp32 / bf16 operands).
+int seq_capacity(const void* kernel, int slot)
+{
+    static int cache[64][4];
+    int dev = 0, cus = 0, per = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
+    if (cache[dev][slot] == 0) {
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, kernel, 256, 0) != hipSuccess) return 0;
+        cache[dev][slot] = (per < 1 ? 0 : per) * (cus < 1 ? 0 : cus);
+        if (cache[dev][slot] == 0) cache[dev][slot] = -1;
+    }
+    return cache[dev][slot] < 0 ? 0 : cache[dev][slot];
+}
+
+// groups per launch for `capacity` resident workgroups under the XCD placement (xt, tpx); 0 = a group does not fit
+int seq_groups_per_launch(int capacity, int ntiles, int xt, int tpx)
+{
+    if (tpx > 0) return capacity / (xt * tpx) / (8 / xt) * (8 / xt);      // grid = 8 tpx workgroups per group class (some idle when ntiles % 8 != 0)
+    int g = capacity / ntiles / 8 * 8;
+    if (g < 8) g = capacity / ntiles;                                    // fewer than 8 groups at a time: still whole groups
+    return g;
+}
+
+void seq_placement(int ntiles, int& xt, int& tpx)
+{
+    static int xt_env = -1;
+    if (xt_env < 0) { const char* e = getenv("PPK_SEQ_XT"); xt_env = e ? atoi(e) : 4; }
+    xt = ntiles >= 8 && (xt_env == 8 || xt_env == 4 || xt_env == 2) ? xt_env : 0;
+    tpx = xt > 0 ? (ntiles + xt - 1) / xt : 0;
+}
+
+// share of a launch's algorithmic work: packed rows of the m-tiles of groups g0 .. g1-1 over all packed rows
+double seq_row_share(const int* bs, int T, int G, int MT, int pair, int g0, int g1)
+{
+    double rows = 0.0, all = 0.0;
+    for (int t = 0; t < T; ++t) {
+        all += bs[t];
+        for (int g = g0; g < g1; ++g) {
+            const int m0 = pair ? 2 * g : g, m1 = pair ? 2 * g + 1 : 2 * G - 1 - g;
+            for (int k = 0; k < 2; ++k) {
+                const int m = k ? m1 : m0;
+                if (k && (m >= MT || m == m0)) continue;
+                const int n = bs[t] - 32 * m;
+                rows += n < 0 ? 0 : (n > 32 ? 32 : n);
+            }
+        }
+    }
+    return all > 0 ? rows / all : 0.0;
+}
+
 bool seq_fwd_persist_ok(int64_t T, int64_t B, int64_t NT, int64_t H, int64_t L, int64_t W, int64_t D, int64_t ks, int64_t ldcs)
 {
     if (force_mode() == 0) return false;
     if (force_mode() == -1 && B < ppk::SEQP_AUTO_MIN_B) return false;       // auto: below this the per-layer-step launches are faster (tools/persist_threshold.py)
     if (T < 1 || T > MAXT || L < 1 || L > MAXL || H % 32 || H > 2048 || ks % 32 || ks > 512 || NT >= (1LL << 31) || B > (1 << 24)) return false;
-    if (ldcs < 3 + W || ldcs % 32) return false;
+    // the workspace (seq_fwd_persist_ws_bytes) is sized for the minimal paddings: a caller with wider ones takes the per-step path
+    if (ldcs != (3 + W + 31) / 32 * 32 || ks != (W + 31) / 32 * 32) return false;
     const int64_t DW4 = (D * W + 3) / 4 * 4;
     if (DW4 + ldcs + ks > REGION) return false;                      // stack-phase scratch: at least one row at a time
     if (32 * ldcs > WL_MAX) return false;                            // the head-weight slice kept in LDS
+    // every workgroup of a group must be resident together: a group that does not fit this device takes the per-step path
+    int xt, tpx;
+    seq_placement((int)(H / 32), xt, tpx);
+    const int cap = ppk::mfma_mode() == 1 ? seq_capacity((const void*)k_seq_fwd<true>, 1) : seq_capacity((const void*)k_seq_fwd<false>, 0);
+    if (seq_groups_per_launch(cap, (int)(H / 32), xt, tpx) < 1) return false;
     return true;
 }
 
@@ -664,16 +756,14 @@ int seq_fwd_persist(int64_t T, const int64_t* bs, int64_t B, int64_t NT, int64_t
                     const float* const* w_ih, const float* const* w_hh, const float* const* b_ih, const float* const* b_hh,
                     const float* wcs, const float* bcs, const float* h0, const float* S0,
                     float* XS, float* Hs, float* HP, float* gates, float* S, float* CS, int64_t ldcs,
-                    void* ws, size_t ws_bytes, hipStream_t stream)
+                    const float* drop, float* Hdrop, void* ws, size_t ws_bytes, hipStream_t stream)
 {
     if (ws_bytes < seq_fwd_persist_ws_bytes(B, H, L, W)) PPK_FAIL(PPK_ERR_WS, "seq_fwd_persist: workspace too small");
     SeqArgs a{};
     a.T = (int)T; a.B = (int)B; a.H = (int)H; a.L = (int)L; a.W = (int)W; a.D = (int)D; a.V = (int)V; a.ks = (int)ks; a.ldcs = (int)ldcs;
     a.ntiles = (int)(H / 32);
     // XCD placement (speed only): xt tile blocks x 8 / xt group classes; xt = 8: tile-major, 0: group-major (PPK_SEQ_XT)
-    { static int xt_env = -1; if (xt_env < 0) { const char* e = getenv("PPK_SEQ_XT"); xt_env = e ? atoi(e) : 4; }
-      a.xt = a.ntiles >= 8 && (xt_env == 8 || xt_env == 4 || xt_env == 2) ? xt_env : 0; }
-    a.tpx = a.xt > 0 ? (a.ntiles + a.xt - 1) / a.xt : 0;          // n-tiles per XCD (0: group-major placement)
+    seq_placement(a.ntiles, a.xt, a.tpx);
     { static int pair_env = -1; if (pair_env < 0) { const char* e = getenv("PPK_SEQ_PAIR"); pair_env = e ? atoi(e) : 0; } a.pair = pair_env; }   // 1: adjacent row blocks per group + mirrored grid halves (measured slower: 18.0 vs 17.3 ms forward; kept for experiments)
     a.MT = (int)((B + 31) / 32);
     a.G = (a.MT + 1) / 2;
@@ -683,6 +773,7 @@ int seq_fwd_persist(int64_t T, const int64_t* bs, int64_t B, int64_t NT, int64_t
     a.bcs = bcs; a.h0 = h0; a.S0 = S0;
     a.dbg = g_dbg;
     a.XS = XS; a.Hs = Hs; a.HP = HP; a.gates = gates; a.S = S; a.CS = CS;
+    a.drop = L > 1 ? drop : nullptr; a.HD = Hdrop;
     for (int t = 0; t < (int)T; ++t) a.bs[t] = (int)bs[t];
     char* cur = (char*)ws;
     float* wcs_t = (float*)ppk_carve(cur, sizeof(float) * (size_t)H * (size_t)ldcs);
@@ -700,21 +791,9 @@ int seq_fwd_persist(int64_t T, const int64_t* bs, int64_t B, int64_t NT, int64_t
     PPK_CHECK_LAUNCH("k_wcs_transpose");
 
     // every workgroup of a group must be resident together: launch at most one machine-full of groups at a time
-    static int capacity = 0;
-    if (capacity == 0) {
-        int dev = 0, cus = 0, per = 0;
-        PPK_HIP(hipGetDevice(&dev));
-        PPK_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-        PPK_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, k_seq_fwd<false>, 256, 0));
-        capacity = std::max(1, per) * std::max(1, cus);
-    }
-    int groups_per_launch;
-    if (a.tpx > 0) {
-        groups_per_launch = capacity / (a.xt * a.tpx) / (8 / a.xt) * (8 / a.xt);                 // grid = 8 tpx workgroups per group (some idle when ntiles % 8 != 0)
-    } else {
-        groups_per_launch = capacity / a.ntiles / 8 * 8;
-        if (groups_per_launch < 8) groups_per_launch = capacity / a.ntiles;      // fewer than 8 groups at a time: still whole groups
-    }
+    const bool bf = ppk::mfma_mode() == 1;
+    const int capacity = bf ? seq_capacity((const void*)k_seq_fwd<true>, 1) : seq_capacity((const void*)k_seq_fwd<false>, 0);
+    const int groups_per_launch = seq_groups_per_launch(capacity, a.ntiles, a.xt, a.tpx);
     if (groups_per_launch < 1) PPK_FAIL(PPK_ERR_UNSUP, "seq_fwd_persist: a group of %d workgroups does not fit the device", a.ntiles);
     const double flops = 2.0 * (double)NT * 3.0 * (double)H * ((double)ks + (2.0 * (double)L - 1.0) * (double)H);
     for (int g0 = 0; g0 < a.G; g0 += groups_per_launch) {
@@ -725,12 +804,16 @@ int seq_fwd_persist(int64_t T, const int64_t* bs, int64_t B, int64_t NT, int64_t
         a.hgrid = a.pair && ng > 1 ? grid_for((ng + 1) / 2) : 0;
         if (2 * a.hgrid > capacity) a.hgrid = 0;                  // rounding of the halves: never more workgroups than are resident together
         const unsigned grid = (unsigned)(a.hgrid > 0 ? 2 * a.hgrid : grid_for(ng));
-        ProfScope prof(PK_SEQ_FWD, flops * (double)ng / (double)a.G, stream);
-        if (ppk::mfma_mode() == 1) k_seq_fwd<true><<<dim3(grid), dim3(256), 0, stream>>>(a);
+        ProfScope prof(PK_SEQ_FWD, flops * seq_row_share(a.bs, a.T, a.G, a.MT, a.pair, a.g0, a.g1), stream);
+        if (bf) k_seq_fwd<true><<<dim3(grid), dim3(256), 0, stream>>>(a);
         else k_seq_fwd<false><<<dim3(grid), dim3(256), 0, stream>>>(a);
         PPK_CHECK_LAUNCH("k_seq_fwd");
     }
-    return PPK_OK;
+    {
+        float* ptrs[5] = {Hs, CS, XS, S, a.drop ? Hdrop : nullptr};
+        const long long counts[5] = {(long long)L * NT * H, NT * ldcs, NT * ks, NT * D * W, (long long)(L - 1) * NT * H};
+        return seq_poison(a.status, ptrs, counts, 5, stream);
+    }
 }
 
 }  // namespace ppk

@@ -45,6 +45,7 @@ struct BwdArgs {
     const float* wx;                                           // [3H, ks] = stack columns of W_ih0, k-major (zero padded)
     const float* wcs_t;                                        // [H, ldcs]
     const float* HP; const float* gates; const float* S; const float* CS; const float* dHtop;
+    const float* drop;                                         // [L-1, NT, H] dropout factors of the forward (null: none)
     float* dXS; float* DGI; float* DGH; float* DCS; float* carry;     // carry = dh0 [L, B, H]
     float* dS;                                                 // [B, D W] stack gradient carried from step to step (rows by sorted index)
     float* xpart;                                              // [(g ntiles + j) 64 + row][ks] partial dXS
@@ -69,51 +70,81 @@ __shared__ long long g_tlast;
 //   accX[s] += Ax_s . Bx^T     accY[s] += Ay_s . By^T
 // SHARE: Ay == Ax (staged once: the dr, dz columns, where dgi == dgh).  accX and accY may be the SAME accumulators
 // (two consecutive K tiles of one product: the caller passes sources 32 columns apart and advances by 64).
+template <int N> struct IntC { static constexpr int v = N; };
+// waits until at most `stages` later stages (PPW loads each) are still in flight; stages in 0 .. 5
+template <int PPW> __device__ __forceinline__ void wait_stages(int stages)
+{
+    switch (stages) {
+        case 0: wait_vmcnt<0>(); break;
+        case 1: wait_vmcnt<PPW>(); break;
+        case 2: wait_vmcnt<2 * PPW>(); break;
+        case 3: wait_vmcnt<3 * PPW>(); break;
+        case 4: wait_vmcnt<4 * PPW>(); break;
+        default: wait_vmcnt<5 * PPW>(); break;
+    }
+}
 template <int NA, bool SHARE, bool BF>
 __device__ __forceinline__ void kloop2(float* lds, const float* x0, const float* x1, const float* y0, const float* y1,
                                        const float* bx, const float* by, int adv, int nst,
                                        f32x16 (&accX)[2], f32x16 (&accY)[2], int wave, int lane)
 {
     constexpr int PPW = 2 + (SHARE ? NA : 2 * NA);
+    // PPK_SEQ_BWD_DEEP: a buffer holds only the blocks this instantiation stages, so the shared region takes 6 / 4 / 3
+    // buffers at 3 / 4 / 6 blocks per stage (twice the bytes in flight while ONE m-tile is active).  Measured equal to
+    // the fixed three-buffer layout in a same-box ABBA run (k_seq_bwd 19.0 vs 18.8 ms per step): the K loops are not
+    // bound by the latency of their staging loads.  Kept as a switch, off.
+#ifndef PPK_SEQ_BWD_DEEP
+    constexpr int SB = STG_BUF, NB = NBUF, OY = 2048, OB = 4096;
+#else
+    constexpr int SB = PPW * 1024, NB = REGION / SB > 6 ? 6 : REGION / SB, OY = NA * 1024, OB = (SHARE ? NA : 2 * NA) * 1024;
+#endif
+    static_assert(NB >= 3 && NB * SB <= REGION && 5 * PPW <= 63, "staging fits the shared region and the vmcnt field");
     const int li = lane & 31, h = lane >> 5;
     const int xo = li * BK + 4 * ((2 * wave + h) ^ ((li >> 1) & 7));
     auto stage = [&](int buf) {
-        float* base = lds + buf * STG_BUF + wave * 256;
+#ifdef PPK_EXP_NODMA
+        return;
+#endif
+        float* base = lds + buf * SB + wave * 256;
         __builtin_amdgcn_global_load_lds(x0, PPK_LDS_PTR(base), 16, 0, 0); x0 += adv;
         if constexpr (NA == 2) { __builtin_amdgcn_global_load_lds(x1, PPK_LDS_PTR(base + 1024), 16, 0, 0); x1 += adv; }
         if constexpr (!SHARE) {
-            __builtin_amdgcn_global_load_lds(y0, PPK_LDS_PTR(base + 2048), 16, 0, 0); y0 += adv;
-            if constexpr (NA == 2) { __builtin_amdgcn_global_load_lds(y1, PPK_LDS_PTR(base + 3072), 16, 0, 0); y1 += adv; }
+            __builtin_amdgcn_global_load_lds(y0, PPK_LDS_PTR(base + OY), 16, 0, 0); y0 += adv;
+            if constexpr (NA == 2) { __builtin_amdgcn_global_load_lds(y1, PPK_LDS_PTR(base + OY + 1024), 16, 0, 0); y1 += adv; }
         }
-        __builtin_amdgcn_global_load_lds(bx, PPK_LDS_PTR(base + 4096), 16, 0, 0); bx += adv;
-        __builtin_amdgcn_global_load_lds(by, PPK_LDS_PTR(base + 5120), 16, 0, 0); by += adv;
+        __builtin_amdgcn_global_load_lds(bx, PPK_LDS_PTR(base + OB), 16, 0, 0); bx += adv;
+        __builtin_amdgcn_global_load_lds(by, PPK_LDS_PTR(base + OB + 1024), 16, 0, 0); by += adv;
     };
     __syncthreads();                                  // the shared region is free
-    // NBUF stages in flight: a buffer is refilled as soon as every wave holds its fragments of it in registers
-    if (nst > 0) stage(0);
-    if (nst > 1) stage(1);
-    if (nst > 2) stage(2);
+    // NB stages in flight: a buffer is refilled as soon as every wave holds its fragments of it in registers
+#pragma unroll
+    for (int p = 0; p < NB; ++p) if (nst > p) stage(p);
     int cur = 0;
     for (int it = 0; it < nst; ++it) {
         const int r = nst - 1 - it;
-        if (r >= 2) wait_vmcnt<2 * PPW>(); else if (r == 1) wait_vmcnt<PPW>(); else wait_vmcnt<0>();
+        wait_stages<PPW>(r < NB - 1 ? r : NB - 1);
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        const float* base = lds + cur * STG_BUF + xo;
+        const float* base = lds + cur * SB + xo;
         Frag<BF> ax[NA], ay[NA], fx, fy;
 #pragma unroll
         for (int s = 0; s < NA; ++s) {
             ax[s].set(*(const f32x4*)(base + s * 1024));
-            if constexpr (!SHARE) ay[s].set(*(const f32x4*)(base + 2048 + s * 1024)); else ay[s] = ax[s];
+            if constexpr (!SHARE) ay[s].set(*(const f32x4*)(base + OY + s * 1024)); else ay[s] = ax[s];
         }
-        fx.set(*(const f32x4*)(base + 4096));
-        fy.set(*(const f32x4*)(base + 5120));
-        if (it + NBUF < nst) {
+        fx.set(*(const f32x4*)(base + OB));
+        fy.set(*(const f32x4*)(base + OB + 1024));
+        if (it + NB < nst) {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();             // every wave has read this buffer
             asm volatile("" ::: "memory");
             stage(cur);
         }
+#ifdef PPK_EXP_NOMMA
+        asm volatile("" :: "v"(ax[0].v), "v"(ay[0].v), "v"(fx.v), "v"(fy.v));
+        if constexpr (NA == 2) asm volatile("" :: "v"(ax[NA - 1].v), "v"(ay[NA - 1].v));
+        if (nst < 0)
+#endif
 #pragma unroll
         for (int st = 0; st < 4; ++st)
 #pragma unroll
@@ -121,7 +152,7 @@ __device__ __forceinline__ void kloop2(float* lds, const float* x0, const float*
                 mma_chunk(accX[s], ax[s], fx, st);
                 mma_chunk(accY[s], ay[s], fy, st);
             }
-        cur = cur == NBUF - 1 ? 0 : cur + 1;
+        cur = cur == NB - 1 ? 0 : cur + 1;
     }
 }
 
@@ -133,6 +164,9 @@ __device__ __forceinline__ void kloop1(float* lds, const float* x0, const float*
     const int li = lane & 31, h = lane >> 5;
     const int xo = li * BK + 4 * ((2 * wave + h) ^ ((li >> 1) & 7));
     auto stage = [&](int buf) {
+#ifdef PPK_EXP_NODMA
+        return;
+#endif
         float* base = lds + buf * STG_BUF + wave * 256;
         __builtin_amdgcn_global_load_lds(x0, PPK_LDS_PTR(base), 16, 0, 0); x0 += BK;
         if constexpr (NA == 2) { __builtin_amdgcn_global_load_lds(x1, PPK_LDS_PTR(base + 1024), 16, 0, 0); x1 += BK; }
@@ -159,6 +193,11 @@ __device__ __forceinline__ void kloop1(float* lds, const float* x0, const float*
             asm volatile("" ::: "memory");
             stage(cur);
         }
+#ifdef PPK_EXP_NOMMA
+        asm volatile("" :: "v"(ax[0].v), "v"(fx.v));
+        if constexpr (NA == 2) asm volatile("" :: "v"(ax[NA - 1].v));
+        if (nk < 0)
+#endif
 #pragma unroll
         for (int st = 0; st < 4; ++st)
 #pragma unroll
@@ -554,6 +593,8 @@ __device__ __forceinline__ bool step_bwd(const BwdArgs& a, float* lds, const int
                     // carry_{l+1} += dgh_{l+1} . W_hh[l+1]  (this workgroup's own tile: plain read-modify-write)
                     float* cp = a.carry + ((long long)(l + 1) * a.B + r0[s] + er) * H + u;
                     st4(cp, ld4(cp) + dump_sum(lds, 1, er, c4));
+                    // layer l + 1 read h_l * drop_l: its input gradient comes back through the same factors (launch-uniform branch)
+                    if (a.drop) dsum *= ld4(a.drop + ((long long)l * a.NT + st.base[s] + er) * H + u);
                 }
                 f32x4 dr, dz, dn;
                 gates_bwd(a, l, st.base[s], r0[s], er, u, pf, dsum, dr, dz, dn);
@@ -682,14 +723,14 @@ __global__ __launch_bounds__(256, 2) void k_seq_bwd(const BwdArgs a)
         }
         const bool ok = st.n[1] > 0 ? step_bwd<2, BF>(a, lds, r0, off, st, t, k, g, j, wave, lane)
                                     : step_bwd<1, BF>(a, lds, r0, off, st, t, k, g, j, wave, lane);
-        if (!ok) { if (threadIdx.x == 0) a.carry[0] = __builtin_nanf(""); return; }      // a hand-off never arrived (status word set): make it visible in the gradient
+        if (!ok) return;      // a hand-off never arrived (status word set; k_seq_poison makes it visible in every output)
     }
     // the stack of step 0 read the INITIAL hidden state of the top layer: dh0[L-1] += DCS_0 . [W_c ; W_s]
     if (Tg > 0) {
         int* ctr = a.ctr + (long long)g * (a.L + 1);
-        if (!group_wait(ctr + a.L, a.ntiles * Tg, a.status, &g_flag)) { if (threadIdx.x == 0) a.carry[0] = __builtin_nanf(""); return; }      // a hand-off never arrived (status word set): make it visible in the gradient
+        if (!group_wait(ctr + a.L, a.ntiles * Tg, a.status, &g_flag)) return;      // a hand-off never arrived (status word set; k_seq_poison makes it visible in every output)
         const int i = 8 * wave + (lane >> 3), li = lane & 31, hh = lane >> 5, er = tid >> 3, c4 = (tid & 7) * 4, u = 32 * j + c4;
-        f32x16 accD[2], accC[2];
+        f32x16 accD[2];
         zero_acc(accD);
         const int n0 = rows(0, 0), n1 = rows(0, 1);
         const float* s0 = a_src(a.DCS, r0[0], n0, a.ldcs, i, lane);
@@ -735,11 +776,16 @@ bool seq_bwd_persist_ok(int64_t T, int64_t B, int64_t NT, int64_t H, int64_t L, 
     if (seq_persist_mode(-2) == 0) return false;
     if (seq_persist_mode(-2) == -1 && B < ppk::SEQP_AUTO_MIN_B) return false;
     if (T < 1 || T > MAXT || L < 1 || L > MAXL || H % 32 || H > 2048 || ks % 32 || ks > 64 || NT >= (1LL << 31) || B > (1 << 24)) return false;
-    if (ldcs < 3 + W || ldcs % 32 || ldcs > 512) return false;
+    // the workspace (seq_bwd_persist_ws_bytes) is sized for the minimal paddings: a caller with wider ones takes the per-step path
+    if (ldcs != (3 + W + 31) / 32 * 32 || ks != (W + 31) / 32 * 32 || ldcs > 512) return false;
     if (NT * 3 * H * 4 >= (1LL << 31)) return false;                // byte offsets of the buffer stores inside one layer's dgi
     const int64_t DW4 = (D * W + 3) / 4 * 4;
     if (4 * DW4 + 8 * ldcs + 4 * ks + 32 > REGION) return false;     // stack-phase scratch: two rows at a time + four rows' heads
     if (6 * 32 * 36 + 96 * ks > REGION) return false;                // dXS-partial scratch
+    int xt, tpx;
+    seq_placement((int)(H / 32), xt, tpx);
+    const int cap = ppk::mfma_mode() == 1 ? seq_capacity((const void*)k_seq_bwd<true>, 3) : seq_capacity((const void*)k_seq_bwd<false>, 2);
+    if (seq_groups_per_launch(cap, (int)(H / 32), xt, tpx) < 1) return false;      // a group does not fit this device: per-step path
     return true;
 }
 
@@ -756,16 +802,14 @@ int seq_bwd_persist(int64_t T, const int64_t* bs, int64_t B, int64_t NT, int64_t
                     const float* const* w_ih_t, const float* const* w_hh_t, const float* wcs_t,
                     const float* HP, const float* gates, const float* S, const float* CS, int64_t ldcs,
                     const float* dHtop, float* dXS, int64_t ks, float* DGI, float* DGH, float* DCS, float* dh0,
-                    void* ws, size_t ws_bytes, hipStream_t stream)
+                    const float* drop, void* ws, size_t ws_bytes, hipStream_t stream)
 {
     if (ws_bytes < seq_bwd_persist_ws_bytes(B, H, L, W, D)) PPK_FAIL(PPK_ERR_WS, "seq_bwd_persist: workspace too small");
     BwdArgs a{};
     a.T = (int)T; a.B = (int)B; a.H = (int)H; a.L = (int)L; a.W = (int)W; a.D = (int)D; a.ks = (int)ks; a.ldcs = (int)ldcs;
     a.ntiles = (int)(H / 32);
     // XCD placement (speed only): xt tile blocks x 8 / xt group classes; xt = 8: tile-major, 0: group-major (PPK_SEQ_XT)
-    { static int xt_env = -1; if (xt_env < 0) { const char* e = getenv("PPK_SEQ_XT"); xt_env = e ? atoi(e) : 4; }
-      a.xt = a.ntiles >= 8 && (xt_env == 8 || xt_env == 4 || xt_env == 2) ? xt_env : 0; }
-    a.tpx = a.xt > 0 ? (a.ntiles + a.xt - 1) / a.xt : 0;          // n-tiles per XCD (0: group-major placement)
+    seq_placement(a.ntiles, a.xt, a.tpx);
     { static int pair_env = -1; if (pair_env < 0) { const char* e = getenv("PPK_SEQ_PAIR"); pair_env = e ? atoi(e) : 0; } a.pair = pair_env; }   // 1: adjacent row blocks per group + mirrored grid halves (measured slower: 18.0 vs 17.3 ms forward; kept for experiments)
     a.MT = (int)((B + 31) / 32);
     a.G = (a.MT + 1) / 2;
@@ -773,6 +817,7 @@ int seq_bwd_persist(int64_t T, const int64_t* bs, int64_t B, int64_t NT, int64_t
     for (int l = 0; l < (int)L; ++l) { a.w_ih_t[l] = w_ih_t[l]; a.w_hh_t[l] = w_hh_t[l]; }
     a.wcs_t = wcs_t;
     a.HP = HP; a.gates = gates; a.S = S; a.CS = CS; a.dHtop = dHtop;
+    a.drop = L > 1 ? drop : nullptr;
     a.dXS = dXS; a.DGI = DGI; a.DGH = DGH; a.DCS = DCS; a.carry = dh0;
     a.dbg = g_dbg;
     for (int t = 0; t < (int)T; ++t) a.bs[t] = (int)bs[t];
@@ -784,31 +829,16 @@ int seq_bwd_persist(int64_t T, const int64_t* bs, int64_t B, int64_t NT, int64_t
     a.xpart = (float*)ppk_carve(cur, sizeof(float) * (size_t)a.G * (size_t)a.ntiles * 64 * (size_t)ks);
     const size_t sbytes = sizeof(float) * (size_t)B * (size_t)D * (size_t)W;
     a.dS = (float*)ppk_carve(cur, sbytes);
-    {
-        const int64_t DW4 = (D * W + 3) / 4 * 4;
-        a.rb = 4;                                     // owned rows per pass of the stack phase (two at a time in LDS)
-    }
+    a.rb = 4;                                         // owned rows per pass of the stack phase (two at a time in LDS)
     PPK_HIP(hipMemsetAsync(ctr, 0, sizeof(int) * nctr, stream));
     PPK_HIP(hipMemsetAsync(a.dS, 0, sbytes, stream));
     PPK_HIP(hipMemsetAsync(dh0, 0, sizeof(float) * (size_t)L * B * H, stream));
     k_wx_transpose<<<dim3((unsigned)std::min<int64_t>((3 * H * ks + 255) / 256, 1024)), dim3(256), 0, stream>>>(w_ih_t[0], (int)W, (int)(3 * H), (int)ks, wx);
     PPK_CHECK_LAUNCH("k_wx_transpose");
 
-    static int capacity = 0;
-    if (capacity == 0) {
-        int dev = 0, cus = 0, per = 0;
-        PPK_HIP(hipGetDevice(&dev));
-        PPK_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-        PPK_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, k_seq_bwd<false>, 256, 0));
-        capacity = std::max(1, per) * std::max(1, cus);
-    }
-    int groups_per_launch;
-    if (a.tpx > 0) {
-        groups_per_launch = capacity / (a.xt * a.tpx) / (8 / a.xt) * (8 / a.xt);
-    } else {
-        groups_per_launch = capacity / a.ntiles / 8 * 8;
-        if (groups_per_launch < 8) groups_per_launch = capacity / a.ntiles;
-    }
+    const bool bf = ppk::mfma_mode() == 1;
+    const int capacity = bf ? seq_capacity((const void*)k_seq_bwd<true>, 3) : seq_capacity((const void*)k_seq_bwd<false>, 2);
+    const int groups_per_launch = seq_groups_per_launch(capacity, a.ntiles, a.xt, a.tpx);
     if (groups_per_launch < 1) PPK_FAIL(PPK_ERR_UNSUP, "seq_bwd_persist: a group of %d workgroups does not fit the device", a.ntiles);
     const double flops = 2.0 * (double)NT * (double)H * (3.0 * (double)H * (2.0 * (double)L - 1.0) + (double)ldcs) + 2.0 * (double)NT * 3.0 * (double)H * (double)ks;
     for (int g0 = 0; g0 < a.G; g0 += groups_per_launch) {
@@ -819,12 +849,16 @@ int seq_bwd_persist(int64_t T, const int64_t* bs, int64_t B, int64_t NT, int64_t
         a.hgrid = a.pair && ng > 1 ? grid_for((ng + 1) / 2) : 0;
         if (2 * a.hgrid > capacity) a.hgrid = 0;                  // rounding of the halves: never more workgroups than are resident together
         const unsigned grid = (unsigned)(a.hgrid > 0 ? 2 * a.hgrid : grid_for(ng));
-        ProfScope prof(PK_SEQ_BWD, flops * (double)ng / (double)a.G, stream);
-        if (ppk::mfma_mode() == 1) k_seq_bwd<true><<<dim3(grid), dim3(256), 0, stream>>>(a);
+        ProfScope prof(PK_SEQ_BWD, flops * seq_row_share(a.bs, a.T, a.G, a.MT, a.pair, a.g0, a.g1), stream);
+        if (bf) k_seq_bwd<true><<<dim3(grid), dim3(256), 0, stream>>>(a);
         else k_seq_bwd<false><<<dim3(grid), dim3(256), 0, stream>>>(a);
         PPK_CHECK_LAUNCH("k_seq_bwd");
     }
-    return PPK_OK;
+    {
+        float* ptrs[5] = {dXS, DGI, DGH, DCS, dh0};
+        const long long counts[5] = {NT * ks, (long long)L * NT * 3 * H, (long long)L * NT * 3 * H, NT * ldcs, (long long)L * B * H};
+        return seq_poison(a.status, ptrs, counts, 5, stream);
+    }
 }
 
 }  // namespace ppk

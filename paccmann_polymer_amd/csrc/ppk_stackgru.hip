@@ -16,11 +16,12 @@
 //   gates [L, NT, 4H] r, z, n, (W_hn h + b_hn)
 //   S     [NT, D, W]  stack after the step           CS [NT, ldcs] softmax(3) | tanh(W)
 //   XS    [NT, ks]    stack top fed to layer 0 (ks = W rounded up to 32, zero padded)
-// The gate contractions are fp32-MFMA GEMMs (ppk_gemm_nt.hip) launched per step
-// with the GRU gate math fused into their epilogues: at batch 2048 each is
-// 3-6 GFLOP, far above the ~1.5 us kernel boundary, while a persistent
-// LDS-resident-weights kernel would pay a 4-6 us grid barrier per layer-step
-// (MI355X_MICROARCH.md price list) — see DESIGN.md.
+// Two launch schedules behind the same entry points (ppk_seq_persist_mode):
+//  * persistent (ppk_seq_persist.hip / ppk_seq_persist_bwd.hip): the whole time loop in ONE launch per pass,
+//    row-block groups synchronised among their own workgroups only — taken from batch 1024 up in auto mode;
+//  * per-step launches (this file): the gate contractions as fp32-MFMA GEMMs (ppk_gemm_nt.hip) with the GRU gate
+//    math fused into their epilogues, 2 + L launches per timestep — faster below batch 1024, where a group's 16
+//    workgroups cannot fill the machine ("Small batches").
 // Per step (forward):   stack update -> {cell 0 (K = ks, + table[token]) ; W_hh[L-1] h of the previous step}
 // -> for l >= 1 {cell l ; W_hh[l-1] h for the NEXT step} -> stack heads for the next step.
 // The embedding half of the layer-0 input product is hoisted out of the time loop:
@@ -233,7 +234,8 @@ int ppk_stackgru_seq_fwd(int64_t T, const int64_t* batch_sizes_host, int64_t B, 
                          const float* const* b_ih, const float* const* b_hh,
                          const float* wcs, const float* bcs, const float* h0, const float* S0,
                          float* XS, float* Hs, float* HP, float* gates, float* S,
-                         float* CS, int64_t ldcs, void* workspace, size_t ws_bytes, hipStream_t stream)
+                         float* CS, int64_t ldcs, const float* drop, float* Hdrop,
+                         void* workspace, size_t ws_bytes, hipStream_t stream)
 {
     SeqDims d{T, B, NT, H, L, W, D, V, ks, ldcs};
     std::vector<int64_t> off;
@@ -242,10 +244,15 @@ int ppk_stackgru_seq_fwd(int64_t T, const int64_t* batch_sizes_host, int64_t B, 
     if (!tokens || !table || !wx0s || !w_ih || !w_hh || !b_ih || !b_hh || !wcs || !bcs || !h0 || !XS || !Hs || !HP || !gates || !S || !CS || !workspace)
         PPK_FAIL(PPK_ERR_NULL, "stackgru_seq_fwd: null pointer");
     if (ws_bytes < ppk_stackgru_seq_fwd_workspace_bytes(B, H, L, W)) PPK_FAIL(PPK_ERR_WS, "stackgru_seq_fwd: workspace too small");
+    if (drop && L > 1 && !Hdrop) PPK_FAIL(PPK_ERR_NULL, "stackgru_seq_fwd: dropout factors without Hdrop");
+    if (L == 1) drop = nullptr;                       // nn.GRU applies dropout between layers only
     // the whole time loop as one persistent launch (ppk_seq_persist.hip) when the shape allows it
     if (ppk::seq_fwd_persist_ok(T, B, NT, H, L, W, D, ks, ldcs))
         return ppk::seq_fwd_persist(T, batch_sizes_host, B, NT, V, H, L, W, D, tokens, table, wx0s, ks, w_ih, w_hh, b_ih, b_hh,
-                                    wcs, bcs, h0, S0, XS, Hs, HP, gates, S, CS, ldcs, workspace, ws_bytes, stream);
+                                    wcs, bcs, h0, S0, XS, Hs, HP, gates, S, CS, ldcs, drop, Hdrop, workspace, ws_bytes, stream);
+    // per-step launches: the carve below follows the ldcs the caller passed (the query assumes the minimal padding)
+    if (ws_bytes < (size_t)L * ppk_align_up(sizeof(float) * (size_t)B * 3 * (size_t)H, 256) + ppk_align_up(sizeof(float) * (size_t)B * (size_t)ldcs, 256))
+        PPK_FAIL(PPK_ERR_WS, "stackgru_seq_fwd: workspace too small for ldcs = %lld", (long long)ldcs);
     char* cur = (char*)workspace;
     std::vector<float*> gh((size_t)L);
     for (int64_t l = 0; l < L; ++l) gh[(size_t)l] = (float*)ppk_carve(cur, sizeof(float) * (size_t)B * 3 * H);
@@ -289,7 +296,8 @@ int ppk_stackgru_seq_fwd(int64_t T, const int64_t* batch_sizes_host, int64_t B, 
             ppk::NtProblem& c = ps[n++];
             c = ppk::NtProblem{};
             if (l == 0) { c.A = XS + o * ks; c.lda = ks; c.K = (int)ks; c.B = wx0s; c.ldb = ks; c.tok = tokens + o; c.table = table; c.V = (int)V; c.bias = nullptr; }
-            else        { c.A = Hs + ((l - 1) * NT + o) * H; c.lda = H; c.K = (int)H; c.B = w_ih[l]; c.ldb = H; c.bias = b_ih[l]; }
+            else        { c.A = (drop ? Hdrop : Hs) + ((l - 1) * NT + o) * H; c.lda = H; c.K = (int)H; c.B = w_ih[l]; c.ldb = H; c.bias = b_ih[l]; }
+            if (drop && l < L - 1) { c.drop = drop + (l * NT + o) * H; c.hdrop = Hdrop + (l * NT + o) * H; }
             c.M = (int)Bt; c.N = (int)H3; c.a_rows = (int)Bt; c.H = (int)H; c.epi = ppk::NT_GRU_FWD;
             c.gh = gh[(size_t)l]; c.hprev = hprev(l);
             c.hnew = Hs + (l * NT + o) * H; c.hp_out = HP + (l * NT + o) * H; c.gates_out = gates + (l * NT + o) * 4 * H;
@@ -329,7 +337,7 @@ int ppk_stackgru_seq_bwd(int64_t T, const int64_t* batch_sizes_host, int64_t B, 
                          const float* const* w_ih_t, const float* const* w_hh_t, const float* wcs_t,
                          const float* HP, const float* gates, const float* S, const float* CS, int64_t ldcs,
                          const float* dHtop, float* dXS, int64_t ks, float* DGI, float* DGH, float* DCS,
-                         float* dh0, void* workspace, size_t ws_bytes, hipStream_t stream)
+                         float* dh0, const float* drop, void* workspace, size_t ws_bytes, hipStream_t stream)
 {
     SeqDims d{T, B, NT, H, L, W, D, 1, ks, ldcs};
     std::vector<int64_t> off;
@@ -338,10 +346,11 @@ int ppk_stackgru_seq_bwd(int64_t T, const int64_t* batch_sizes_host, int64_t B, 
     if (!w_ih_t || !w_hh_t || !wcs_t || !HP || !gates || !S || !CS || !dHtop || !dXS || !DGI || !DGH || !DCS || !dh0 || !workspace)
         PPK_FAIL(PPK_ERR_NULL, "stackgru_seq_bwd: null pointer");
     if (ws_bytes < ppk_stackgru_seq_bwd_workspace_bytes(B, H, L, W, D)) PPK_FAIL(PPK_ERR_WS, "stackgru_seq_bwd: workspace too small");
+    if (L == 1) drop = nullptr;
     // the whole time loop as one persistent launch (ppk_seq_persist_bwd.hip) when the shape allows it
     if (ppk::seq_bwd_persist_ok(T, B, NT, H, L, W, D, ks, ldcs))
         return ppk::seq_bwd_persist(T, batch_sizes_host, B, NT, H, L, W, D, w_ih_t, w_hh_t, wcs_t, HP, gates, S, CS, ldcs,
-                                    dHtop, dXS, ks, DGI, DGH, DCS, dh0, workspace, ws_bytes, stream);
+                                    dHtop, dXS, ks, DGI, DGH, DCS, dh0, drop, workspace, ws_bytes, stream);
     char* cur = (char*)workspace;
     const size_t sbytes = sizeof(float) * (size_t)B * D * W;
     float* dSa = (float*)ppk_carve(cur, sbytes);
@@ -378,7 +387,10 @@ int ppk_stackgru_seq_bwd(int64_t T, const int64_t* batch_sizes_host, int64_t B, 
             const float* dgh = DGH + (l * NT + o) * H3;
             ppk::NtProblem ps[2];
             ps[0] = nt_store(dgh, H3, Bt, w_hh_t[l], H3, H, H3, dh0 + l * B * H, H, nullptr, 1.f, H);      // carry_l += dgh . W_hh
-            if (l > 0) ps[1] = gru_bwd_problem(dgi, H3, Bt, w_ih_t[l], H3, H3, l - 1, Bt, o, nullptr);     // dh_{l-1} = carry + dgi . W_ih
+            if (l > 0) {
+                ps[1] = gru_bwd_problem(dgi, H3, Bt, w_ih_t[l], H3, H3, l - 1, Bt, o, nullptr);            // dh_{l-1} = carry + (dgi . W_ih) * drop_{l-1}
+                if (drop) ps[1].drop = drop + ((l - 1) * NT + o) * H;
+            }
             else       ps[1] = nt_store(dgi, H3, Bt, w_ih_t[0], H3, W, H3, dXS + o * ks, ks, nullptr, 0.f, H);
             rc = ppk::gemm_nt64(ps, 2, stream);
             if (rc) return rc;
@@ -394,8 +406,9 @@ int ppk_stackgru_seq_bwd(int64_t T, const int64_t* batch_sizes_host, int64_t B, 
     return ppk::gemm_nt64(&p, 1, stream);
 }
 
-// Test / tuning hook: -1 = the persistent sequence kernels run whenever the shape allows (default), 0 = never
-// (per-timestep launches), 1 = same as -1; any other value only queries.  Returns the value in force.
+// Launch schedule of the sequence entry points: -1 = auto (default: the persistent kernels from batch
+// ppk::SEQP_AUTO_MIN_B = 1024 up, where they are faster; the per-step launches below), 0 = never persistent,
+// 1 = persistent whenever the shape is supported, at any batch; any other value only queries.  Returns the value in force.
 int ppk_seq_persist_mode(int mode) { return ppk::seq_persist_mode(mode); }
 int ppk_mfma_mode(int mode) { return ppk::mfma_mode(mode); }
 

@@ -328,6 +328,18 @@ class DeepGraphInfomax(nn.Module):
     def loss(self, pos_z, neg_z, summary):
         return _DGILoss.apply(self._logits(pos_z, summary), self._logits(neg_z, summary))
 
+    def test(self, train_z, train_y, test_z, test_y, solver='lbfgs', multi_class='auto', *args, **kwargs):
+        """torch_geometric's `DeepGraphInfomax.test` (the Planetoid baselines call it,
+        experiments/cora/infomax.py): accuracy of a logistic regression fitted on the frozen latents.  Host-side
+        scikit-learn exactly as upstream does it; `multi_class` is forwarded only where the installed
+        scikit-learn still takes it (removed from LogisticRegression in 1.7; 'auto' was its default)."""
+        import inspect
+        from sklearn.linear_model import LogisticRegression
+        if 'multi_class' in inspect.signature(LogisticRegression.__init__).parameters and multi_class != 'auto':
+            kwargs['multi_class'] = multi_class
+        clf = LogisticRegression(solver=solver, *args, **kwargs).fit(train_z.detach().cpu().numpy(), train_y.detach().cpu().numpy())
+        return clf.score(test_z.detach().cpu().numpy(), test_y.detach().cpu().numpy())
+
 
 class GraphEncoder(nn.Module):
     """reactions_infomax.py:38-83 with the frozen sequence encoder factored out:

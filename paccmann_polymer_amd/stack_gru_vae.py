@@ -179,6 +179,18 @@ def linear(x, weight, bias=None):
     return _Linear.apply(x, weight, bias)
 
 
+class HIPLinear(nn.Linear):
+    """`nn.Linear` whose call runs the fp32-MFMA GEMM of libppk.so (same parameters, same `state_dict` keys).  The
+    reference's in-tree callers apply these layers directly — `decoder.latent_to_hidden(latent_z)`,
+    `decoder.output_layer(output)` (experiments/latent_space_exploration/latent_space_map_fns.py:288,306) — on
+    tensors with leading batch dimensions."""
+
+    def forward(self, x):
+        lead = x.shape[:-1]
+        y = linear(x.reshape(-1, x.shape[-1]).to(torch.float32), self.weight, self.bias)
+        return y.reshape(*lead, self.out_features)
+
+
 def _round_up(x, m):
     return (x + m - 1) // m * m
 
@@ -211,6 +223,35 @@ def _unpad_units(t, H, Hp, dim, gates=1):
 def _gemm(ta, tb, M, N, K, A, lda, Bm, ldb, C, ldc, bias=None, ws=None, wsb=0):
     _C.check(_lib.ppk_gemm_f32(ta, tb, M, N, K, 1.0, _C.p(A), lda, _C.p(Bm), ldb, 0.0, _C.p(C), ldc,
                                _C.p(bias), _C.p(ws), wsb, _C.stream()))
+
+
+def _rowsum_by_token(tokens, V, rows):
+    """[V, F] = the rows of `rows` [NT, F] summed per token id, in a fixed order (ppk_rowsum_by_key: sort-free stable
+    counting sort + chunked partial sums; bitwise reproducible).  Replaces the dense one-hot product
+    [V x NT] . [NT x 3H] of round 2 (2 NT V 3H FLOP: 219 GFLOP at the pretrained language's V = 575).  Vocabularies
+    beyond the kernel's 8192 LDS bins go through K6 + K7 (ppk_csr_build_rect, ppk_spmm_csr_ws): same fixed-order sums."""
+    dev = rows.device
+    NT, F = rows.shape
+    out = torch.empty(V, F, dtype=torch.float32, device=dev)
+    status = torch.zeros(1, dtype=torch.int32, device=dev)
+    if V <= 8192:
+        wsb = _lib.ppk_rowsum_by_key_workspace_bytes(NT, V, F)
+        ws = _ws(wsb, dev)
+        _C.check(_lib.ppk_rowsum_by_key(_C.p(tokens), NT, V, _C.p(rows), rows.stride(0), F, _C.p(out), F, _C.p(status), _C.p(ws), wsb, _C.stream()))
+        return out
+    idx = torch.arange(NT, dtype=torch.int64, device=dev)
+    rowptr = torch.empty(V + 1, dtype=torch.int64, device=dev)
+    col = torch.zeros(NT, dtype=torch.int64, device=dev)
+    eid = torch.empty(NT, dtype=torch.int64, device=dev)
+    val = torch.zeros(NT, dtype=torch.float32, device=dev)
+    wsb = _lib.ppk_csr_build_workspace_bytes(V, NT)
+    ws = _ws(wsb, dev)
+    _C.check(_lib.ppk_csr_build_rect(_C.p(idx), _C.p(tokens), NT, V, NT, 0, 0, 0, None, _C.p(rowptr), _C.p(col), _C.p(eid), _C.p(val),
+                                     _C.p(status), _C.p(ws), wsb, _C.stream()))
+    sws_b = _lib.ppk_spmm_csr_workspace_bytes(V, NT, F)
+    sws = _ws(sws_b, dev)
+    _C.check(_lib.ppk_spmm_csr_ws(_C.p(rowptr), _C.p(col), _C.p(val), V, NT, _C.p(rows), rows.stride(0), F, _C.p(out), F, _C.p(sws), sws_b, _C.stream()))
+    return out
 
 
 def _seq_forward(tokens, batch_sizes, dims, h0, S0, emb, wc, bc, wsi, bsi, gru):
@@ -357,10 +398,9 @@ class _StackGRUSeq(torch.autograd.Function):
         def w_grad(g):          # [3Hp, Hp] -> [3H, H]
             return _unpad_units(_unpad_units(g, H, Hp, 0, 3), H, Hp, 1)
 
-        # layer 0: stack columns from XS; embedding columns through the per-token table
-        onehot = torch.zeros(NT, V, **f32)
-        onehot.scatter_(1, tokens.view(-1, 1), 1.0)
-        dtable = tn(onehot, V, V, DGI[0], 3 * Hp, 3 * Hp)                     # [V, 3Hp] rows of DGI0 summed per token
+        # layer 0: stack columns from XS; embedding columns through the per-token table:
+        # dtable[v] = sum of the rows of DGI0 whose token is v, in ascending row order (K6 + K7, bitwise reproducible)
+        dtable = _rowsum_by_token(tokens, V, DGI[0])                          # [V, 3Hp]
         dw0s = tn(DGI[0], 3 * Hp, 3 * Hp, XS, ks, W)                          # [3Hp, W]
         dw0e = tn(dtable, 3 * Hp, 3 * Hp, embc, E, E, K=V)                    # [3Hp, E] = dtable^T . emb
         demb = torch.empty(V, E, **f32)
@@ -410,8 +450,8 @@ class StackGRU(nn.Module):
         self.embedding = nn.Embedding(self.vocab_size, self.embedding_size, padding_idx=self.padding_index)
         self.gru = nn.GRU(self.embedding_size + self.stack_width, self.rnn_cell_size, self.n_layers,
                           dropout=self.dropout)
-        self.stack_controls_layer = nn.Linear(self.rnn_cell_size, 3)
-        self.stack_input_layer = nn.Linear(self.rnn_cell_size, self.stack_width)
+        self.stack_controls_layer = HIPLinear(self.rnn_cell_size, 3)
+        self.stack_input_layer = HIPLinear(self.rnn_cell_size, self.stack_width)
 
     # upstream API kept for drop-in callers (reactions_vae.py:62-63,177)
     def _update_batch_size(self, batch_size: int):
@@ -468,6 +508,17 @@ class StackGRU(nn.Module):
         return (torch.zeros(self.n_layers, B, self.rnn_cell_size, dtype=torch.float32, device=dev),
                 torch.zeros(B, self.stack_depth, self.stack_width, dtype=torch.float32, device=dev))
 
+    # upstream attributes (`_update_batch_size` re-allocates them, which is why the reference calls it
+    # before every step, reactions_vae.py:62-63; read by latent_space_map_fns.py:289).  Here they follow `batch_size`
+    # and the module's current device by construction.
+    @property
+    def init_hidden(self):
+        return self.init_state()[0]
+
+    @property
+    def init_stack(self):
+        return self.init_state()[1]
+
     def forward(self, token, hidden, stack):
         """One StackGRU step (the call of paccmann_chemistry's generation loop that the
         reference reaches through paccmann_encoder.py:115-131): token [1, B] or [B] int64, hidden [L, B, H],
@@ -513,8 +564,8 @@ class StackGRUEncoder(StackGRU):
     def __init__(self, params):
         super().__init__(params)
         self.latent_dim = self.params['latent_dim']
-        self.hidden_to_mu = nn.Linear(self.rnn_cell_size, self.latent_dim)
-        self.hidden_to_logvar = nn.Linear(self.rnn_cell_size, self.latent_dim)
+        self.hidden_to_mu = HIPLinear(self.rnn_cell_size, self.latent_dim)
+        self.hidden_to_logvar = HIPLinear(self.rnn_cell_size, self.latent_dim)
 
     def encoder_train_step(self, packed: PackedSequence):
         """-> (mu, logvar) [B, Z] in ORIGINAL sample order."""
@@ -535,8 +586,8 @@ class StackGRUDecoder(StackGRU):
     def __init__(self, params):
         super().__init__(params)
         self.latent_dim = self.params['latent_dim']
-        self.latent_to_hidden = nn.Linear(self.latent_dim, self.rnn_cell_size)
-        self.output_layer = nn.Linear(self.rnn_cell_size, self.vocab_size)
+        self.latent_to_hidden = HIPLinear(self.latent_dim, self.rnn_cell_size)
+        self.output_layer = HIPLinear(self.rnn_cell_size, self.vocab_size)
 
     def decoder_train_step(self, latent_z, packed_in: PackedSequence, packed_tgt: PackedSequence):
         """latent_z [1 or L, B, Z] in ORIGINAL sample order -> mean CE over non-pad targets."""
@@ -629,7 +680,7 @@ class TeacherVAE(nn.Module):
         with torch.no_grad():
             z = latent_z.reshape(-1, latent_z.shape[-1]).to(dec.embedding.weight.device, torch.float32)
             B = z.shape[0]
-            h = linear(z, dec.latent_to_hidden.weight, dec.latent_to_hidden.bias)
+            h = dec.latent_to_hidden(z)
             hidden = h.unsqueeze(0).repeat(dec.n_layers, 1, 1).contiguous()
             _, stack = dec.init_state(B)
             token = prime_input.reshape(-1)[:1].to(z.device, torch.int64).repeat(B)
@@ -637,7 +688,7 @@ class TeacherVAE(nn.Module):
             out_tokens = []
             for _ in range(int(generate_len)):
                 out, hidden, stack = dec(token, hidden, stack)
-                logits = linear(out.squeeze(0).contiguous(), dec.output_layer.weight, dec.output_layer.bias)
+                logits = dec.output_layer(out.squeeze(0))
                 token = search.step(logits).reshape(-1).to(torch.int64)
                 out_tokens.append(token)
             tokens = torch.stack(out_tokens, dim=1).cpu() if out_tokens else torch.zeros(B, 0, dtype=torch.int64)

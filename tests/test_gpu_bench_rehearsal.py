@@ -13,10 +13,13 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def test_two_rank_bench_line():
+@pytest.mark.parametrize('dtype,port', [('f32', '29561'), ('bf16', '29563')])
+def test_two_rank_bench_line(dtype, port):
+    """dtype bf16 = BASELINE configs[4]'s arithmetic (ppk_mfma_mode(1) on every rank): the launch the driver would use
+    with `--gpus 8 --dtype bf16`, at two ranks."""
     env = dict(os.environ, PPK_BENCH_REHEARSAL='1')
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
-           '--master-port', '29561', os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1']
+           '--master-port', port, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1', '--dtype', dtype]
     out = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=280)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith('{')]
@@ -26,3 +29,4 @@ def test_two_rank_bench_line():
     assert rec['config']['global_batch'] == 4096 and rec['config']['parallelism'] == 'dp2'
     assert rec['value'] > 0 and abs(rec['value'] - 4096 / (rec['ms_per_step'] * 1e-3)) <= 1e-2 * rec['value']
     assert 'cpu_baseline' not in rec and 'rehearsal' in rec
+    assert rec['dtype'] == dtype

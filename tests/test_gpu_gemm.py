@@ -120,3 +120,39 @@ def test_gemm_tn_colsum_unsupported_shape_launches_nothing():
     assert rc == _C.PPK_ERR_UNSUP
     torch.cuda.synchronize()
     assert bool((C == 7.0).all()) and bool((cs == 7.0).all())
+
+
+@pytest.mark.parametrize('n_rows,n_keys,F', [(5000, 575, 96), (124072, 64, 1536), (3000, 3000, 64), (777, 8192, 8), (1, 1, 4)])
+def test_rowsum_by_key_vs_fp64_index_add(n_rows, n_keys, F):
+    """ppk_rowsum_by_key (the embedding-table gradient of K1): rows summed per key in a fixed order — against fp64
+    index_add_, bitwise reproducible, skewed key frequencies (a hub key holding a fifth of the rows), empty keys,
+    an out-of-range key reported through `status` and skipped."""
+    from paccmann_polymer_amd import _C
+    lib = _C.lib
+    g = torch.Generator().manual_seed(n_rows + n_keys)
+    p = 1.0 / torch.arange(1, n_keys + 1, dtype=torch.float64)
+    keys = torch.multinomial(p / p.sum(), n_rows, replacement=True, generator=g).cuda()
+    x = torch.randn(n_rows, F, generator=g).cuda()
+    wsb = lib.ppk_rowsum_by_key_workspace_bytes(n_rows, n_keys, F)
+    ws = torch.empty(max(wsb, 256), dtype=torch.uint8, device='cuda')
+
+    def run(k):
+        out = torch.full((n_keys, F), float('nan'), device='cuda')
+        status = torch.zeros(1, dtype=torch.int32, device='cuda')
+        _C.check(lib.ppk_rowsum_by_key(_C.p(k), n_rows, n_keys, _C.p(x), F, F, _C.p(out), F, _C.p(status), _C.p(ws), wsb, _C.stream()))
+        return out, int(status)
+    a, st = run(keys)
+    b, _ = run(keys)
+    assert st == 0 and torch.equal(a, b)
+    ref = torch.zeros(n_keys, F, dtype=torch.float64, device='cuda').index_add_(0, keys, x.double())
+    scale = torch.zeros(n_keys, F, dtype=torch.float64, device='cuda').index_add_(0, keys, x.double().abs())
+    assert float(((a.double() - ref).abs() / (scale + 1.0)).max()) <= 2e-6
+    if n_rows > 10:
+        bad = keys.clone()
+        bad[3] = n_keys
+        bad[7] = -1
+        c, st = run(bad)
+        ok = torch.ones(n_rows, dtype=torch.bool, device='cuda')
+        ok[3] = ok[7] = False
+        ref2 = torch.zeros(n_keys, F, dtype=torch.float64, device='cuda').index_add_(0, keys[ok], x[ok].double())
+        assert st != 0 and float(((c.double() - ref2).abs() / (scale + 1.0)).max()) <= 2e-6

@@ -62,6 +62,57 @@ def test_greedy_generation_matches_oracle_loop():
         assert g.tolist() == w.tolist()
 
 
+def _decode_logits_statements(gru_vae, latent_z, start_index, stop_index, device, generate_len=50, temperature=1):
+    """The statements of the reference's `decode_logits`
+    (experiments/latent_space_exploration/latent_space_map_fns.py:273-314) — the ONLY code in the reference tree that
+    shows how the third-party decoder is stepped: `_update_batch_size`, `latent_z.repeat(n_layers, 1, 1)`,
+    `latent_to_hidden(latent_z)` applied to the [L, B, Z] tensor, `init_stack`, priming loop, `decoder(token, hidden,
+    stack)`, `output_layer(output).squeeze()`, softmax over the tokens.  Kept statement for statement; the two
+    deviations: `latent_z` keeps its dtype (the reference casts to float32: the oracle runs in float64) and
+    `.detach().numpy()` reads through `.cpu()` (the reference runs this on the CPU)."""
+    latent_z = torch.as_tensor(latent_z).view(1, latent_z.shape[0], latent_z.shape[1]).to(device)
+    prime_input = torch.tensor([start_index]).to(device)
+    batch_size = latent_z.shape[1]
+    gru_vae.decoder._update_batch_size(batch_size)
+    latent_z = latent_z.repeat(gru_vae.decoder.n_layers, 1, 1)
+    hidden = gru_vae.decoder.latent_to_hidden(latent_z)
+    stack = gru_vae.decoder.init_stack
+    generated_seq = prime_input.repeat(batch_size, 1)
+    prime_input = generated_seq.transpose(1, 0).unsqueeze(1)
+    for prime_entry in prime_input[:-1]:
+        _, hidden, stack = gru_vae.decoder(prime_entry, hidden, stack)
+    input_token = prime_input[-1]
+    logits_list, probabilities_list = [], []
+    for idx in range(generate_len):
+        output, hidden, stack = gru_vae.decoder(input_token, hidden, stack)
+        logits = gru_vae.decoder.output_layer(output).squeeze()
+        probabilities = torch.softmax(logits.div(temperature), dim=0)
+        logits_list.append(logits.detach().cpu().numpy())
+        probabilities_list.append(probabilities.detach().cpu().numpy())
+    return np.stack(logits_list), np.stack(probabilities_list).astype(np.double)
+
+
+def test_reference_decode_logits_statements_on_hip_decoder_and_oracle():
+    """Replays `decode_logits` on the HIP decoder and on oracle/stackgru_ref.py with the same weights: every attribute
+    and call of the upstream decoder that the reference's own code uses exists with the shapes it expects, and the
+    two agree on the logits of every step (the reference feeds the start token at EVERY step — `input_token` is never
+    updated — so 12 steps carry hidden state and stack through 12 stack updates)."""
+    ref, gpu = build()
+    rng = np.random.default_rng(9)
+    z = rng.standard_normal((1, 6))                              # decode_logits requires latent_z.shape[0] == 1 (:271-272)
+    with torch.no_grad():
+        want_l, want_p = _decode_logits_statements(ref, torch.tensor(z), 2, 3, 'cpu', generate_len=12, temperature=0.7)
+        got_l, got_p = _decode_logits_statements(gpu, torch.tensor(z).float(), 2, 3, 'cuda', generate_len=12, temperature=0.7)
+    assert got_l.shape == want_l.shape == (12, PARAMS['vocab_size'])
+    assert np.linalg.norm(got_l - want_l) <= 1e-5 * np.linalg.norm(want_l)
+    assert np.abs(got_p - want_p).max() <= 1e-5 and np.allclose(got_p.sum(1), 1.0, atol=1e-5)
+    # the attributes themselves
+    gpu.decoder._update_batch_size(7)
+    assert gpu.decoder.init_stack.shape == (7, PARAMS['stack_depth'], PARAMS['stack_width']) and gpu.decoder.init_stack.is_cuda
+    assert gpu.decoder.init_hidden.shape == (PARAMS['n_layers'], 7, PARAMS['rnn_cell_size']) and float(gpu.decoder.init_hidden.abs().sum()) == 0.0
+    assert gpu.encoder.init_stack.shape[0] == gpu.encoder.batch_size
+
+
 def test_encoder_facade_decode_and_reconstruct():
     from paccmann_polymer_amd.paccmann_encoder import Encoder
     from torch.nn.utils.rnn import pack_sequence

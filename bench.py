@@ -32,10 +32,10 @@ PEAK_BF16_MFMA_TFLOPS = 2500.0     # dense bf16 MFMA (the figure without 2:1 spa
 PEAK_HBM_GBS = 8000.0
 
 
-def synth_batch(rng, n_bundles, bundle_nodes, lo=20, hi=100, vocab=64):
+def synth_batch(rng, n_bundles, bundle_nodes, lo=20, hi=100, vocab=64, return_edges=False):
     """Synthetic SMILES token lists + per-bundle relation graphs (random tree + a few chords, <= 20 edges)."""
     from paccmann_polymer_amd.data_prep import hop_distance_matrix
-    seqs, gs, sizes = [], [], []
+    seqs, gs, sizes, eis = [], [], [], []
     for _ in range(n_bundles):
         n = bundle_nodes
         edges = [[int(rng.integers(0, v)), v] for v in range(1, n)]
@@ -45,10 +45,13 @@ def synth_batch(rng, n_bundles, bundle_nodes, lo=20, hi=100, vocab=64):
                 edges.append([int(a), int(b)])
         ei = np.asarray(edges, dtype=np.int64).T
         gs.append(hop_distance_matrix(ei, n, order='networkx'))
+        eis.append(ei)
         sizes.append(n)
         for _ in range(n):
             L = int(rng.integers(lo, hi + 1))
             seqs.append(torch.tensor(np.concatenate([[2], rng.integers(4, vocab, size=L - 2), [3]]), dtype=torch.int64))
+    if return_edges:
+        return seqs, gs, sizes, eis
     return seqs, gs, sizes
 
 

@@ -87,8 +87,8 @@ class StackGRURef(nn.Module):
         stack_up = torch.cat((input_val.unsqueeze(1), prev_stack[:, :-1]), dim=1)
         return a_no_op * prev_stack + a_push * stack_up + a_pop * stack_down
 
-    def forward(self, token, hidden, stack):
-        # token [1, B] int64, hidden [L, B, H], stack [B, D, W]
+    def forward(self, token, hidden, stack, drop=None):
+        # token [1, B] int64, hidden [L, B, H], stack [B, D, W]; drop [L-1, B, H] injected dropout factors (None: self.gru as is)
         emb = self.embedding(token)                                       # [1, B, E]
         if self.use_stack:
             top = hidden[-1]
@@ -96,8 +96,30 @@ class StackGRURef(nn.Module):
             s_in = torch.tanh(self.stack_input_layer(top))
             stack = self.stack_augmentation(s_in, stack, controls)
             emb = torch.cat((emb, stack[:, 0, :].unsqueeze(0)), dim=2)
-        out, hidden = self.gru(emb, hidden)
+        if drop is None:
+            out, hidden = self.gru(emb, hidden)
+        else:
+            out, hidden = self.gru_layers_with_factors(emb, hidden, drop)
         return out, hidden, stack
+
+    def gru_layers_with_factors(self, x, hidden, drop):
+        """nn.GRU(seq_len = 1, dropout = p) in training mode with the dropout FACTORS injected (SURVEY landmine 10: the
+        device and the CPU cannot share noise): drop [L-1, B, H] holds 0 or 1 / (1 - p); torch applies dropout to the
+        output of every layer except the last, on the way to the next layer only.  The cell is torch's own
+        (`torch.gru_cell` on the module's weights); with all factors 1 this equals `self.gru(x, hidden)`
+        (tests/test_oracle_dropout.py)."""
+        inp = x.squeeze(0)
+        new_h = []
+        for l in range(self.n_layers):
+            w_ih, w_hh = getattr(self.gru, f'weight_ih_l{l}'), getattr(self.gru, f'weight_hh_l{l}')
+            b_ih, b_hh = getattr(self.gru, f'bias_ih_l{l}'), getattr(self.gru, f'bias_hh_l{l}')
+            h = torch.gru_cell(inp, hidden[l], w_ih, w_hh, b_ih, b_hh)
+            new_h.append(h)
+            inp = h * drop[l] if l < self.n_layers - 1 else h
+        hidden = torch.stack(new_h, dim=0)
+        return hidden[-1].unsqueeze(0), hidden
+
+    drop_factors = None       # [L-1, NT, H] in packed-row order: injected dropout factors for the next run_packed calls
 
     def run_packed(self, packed: PackedSequence, hidden, stack):
         """Steps through a PackedSequence.  `hidden`/`stack` are in SORTED order.
@@ -114,7 +136,8 @@ class StackGRURef(nn.Module):
                 hidden = hidden[:, :b]
                 stack = stack[:b]
             tok = data[off:off + b].unsqueeze(0)
-            out, hidden, stack = self.forward(tok, hidden, stack)
+            drop = None if self.drop_factors is None else self.drop_factors[:, off:off + b]
+            out, hidden, stack = self.forward(tok, hidden, stack, drop)
             outs.append(out.squeeze(0))
             off += b
             prev_b = b

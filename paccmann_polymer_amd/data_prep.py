@@ -85,6 +85,14 @@ def _packed_preparation_vectorised(input_batch, device):
     loop over samples: one concatenation, one sort (the same `torch.sort(lengths, descending=True)` that
     `pack_sequence(enforce_sorted=False)` performs, so ties order identically) and index arithmetic.  At batch
     2048 the per-sample path costs 75 ms on the host — longer than the whole GPU step — this one ~4 ms."""
+    return packed_preparation_to_device(packed_preparation_host(input_batch), device)
+
+
+def packed_preparation_host(input_batch, pin=False):
+    """Host half of `_packed_preparation_vectorised` (input_keep == 1): everything that is index arithmetic, as CPU
+    tensors (pinned when `pin`: an asynchronous copy engine transfer needs page-locked memory).  A worker thread can
+    run it for batch t + 1 while the GPU works on batch t (trainer.train_bundled); `packed_preparation_to_device`
+    is the other half."""
     lengths = torch.tensor([int(x.numel()) for x in input_batch], dtype=torch.int64)
     flat = torch.cat([x.reshape(-1) for x in input_batch]).long().cpu()
     starts = torch.cumsum(lengths, 0) - lengths
@@ -92,24 +100,34 @@ def _packed_preparation_vectorised(input_batch, device):
     unsorted_idx = torch.empty_like(sorted_idx)
     unsorted_idx[sorted_idx] = torch.arange(sorted_idx.numel(), dtype=torch.int64)
     T = int(sorted_len[0])
-    valid = torch.arange(T, dtype=torch.int64).view(T, 1) < sorted_len.view(1, -1)        # [T, B] time-major
+    valid = torch.arange(T, dtype=torch.int64).view(T, 1) < sorted_len.view(1, -1)
     batch_sizes = valid.sum(1)
-    t_idx, i_idx = valid.nonzero(as_tuple=True)                                           # row-major = packed order
+    t_idx, i_idx = valid.nonzero(as_tuple=True)
     src = starts[sorted_idx[i_idx]] + t_idx
     data = flat[src]
-    # target = input shifted left by one inside every sequence, 0 in its last slot
     last = t_idx + 1 >= sorted_len[i_idx]
     tgt = flat[torch.where(last, src, src + 1)]
     tgt = torch.where(last, torch.zeros_like(tgt), tgt)
-    data_d, tgt_d = data.to(device), tgt.to(device)
+    out = dict(data=data, tgt=tgt, sorted_idx=sorted_idx, unsorted_idx=unsorted_idx)
+    if pin and torch.cuda.is_available():
+        out = {k: v.pin_memory() for k, v in out.items()}
+    out.update(batch_sizes=batch_sizes, lo=int(flat.min()), hi=int(flat.max()))
+    return out
+
+
+def packed_preparation_to_device(host, device, non_blocking=False):
+    """[encoder_seq, decoder_seq, target_seq] on `device` from `packed_preparation_host`'s tensors."""
+    data_d = host['data'].to(device, non_blocking=non_blocking)
+    tgt_d = host['tgt'].to(device, non_blocking=non_blocking)
     dec_d = data_d.clone()
-    lo, hi = int(flat.min()), int(flat.max())
+    lo, hi = host['lo'], host['hi']
     note_token_range(data_d, lo, hi)
     note_token_range(dec_d, lo, hi)
     note_token_range(tgt_d, min(lo, 0), hi)
-    si, ui = sorted_idx.to(device), unsorted_idx.to(device)
-    return [PackedSequence(data_d, batch_sizes, si, ui), PackedSequence(dec_d, batch_sizes, si, ui),
-            PackedSequence(tgt_d, batch_sizes, si, ui)]
+    si = host['sorted_idx'].to(device, non_blocking=non_blocking)
+    ui = host['unsorted_idx'].to(device, non_blocking=non_blocking)
+    bs = host['batch_sizes']
+    return [PackedSequence(data_d, bs, si, ui), PackedSequence(dec_d, bs, si, ui), PackedSequence(tgt_d, bs, si, ui)]
 
 
 def _packed_preparation_device(input_batch, device):
@@ -224,9 +242,18 @@ def hop_distance_matrices_device(edge_indices, num_nodes, order: str = 'networkx
     sizes = [int(n) for n in num_nodes]
     if len(sizes) != len(edge_indices) or not sizes:
         raise ValueError()
+    host = hop_inputs_host(edge_indices, sizes)
+    return hop_distances_launch(host, order, device)
+
+
+def hop_inputs_host(edge_indices, num_nodes, pin=False):
+    """Host half of `hop_distance_matrices_device`: label validation (IndexError, where the edge lists still are host
+    data: reading the kernel's status word back would cost a device-to-host sync per step) and ONE flat int64 array
+    [esrc | edst | edge_ptr | seg_ptr | mat_ptr] for a single host-to-device copy."""
+    sizes = [int(n) for n in num_nodes]
+    if len(sizes) != len(edge_indices) or not sizes:
+        raise ValueError()
     eis = [np.asarray(e.cpu() if torch.is_tensor(e) else e, dtype=np.int64).reshape(2, -1) for e in edge_indices]
-    # labels are validated HERE, where the edge lists still are host data: reading the kernel's status word back would
-    # cost one device-to-host sync per bundle of trainer.train() (the kernel still skips bad edges and raises it)
     for e, n in zip(eis, sizes):
         if e.size and (int(e.min()) < 0 or int(e.max()) >= n):
             raise IndexError('edge_index holds a node label outside [0, num_nodes)')
@@ -236,15 +263,24 @@ def hop_distance_matrices_device(edge_indices, num_nodes, order: str = 'networkx
     seg_ptr[1:] = np.cumsum(sizes)
     mat_ptr = np.zeros(len(sizes) + 1, dtype=np.int64)
     mat_ptr[1:] = np.cumsum([n * n for n in sizes])
-    packed = np.concatenate([np.concatenate(eis, axis=1).reshape(-1), edge_ptr, seg_ptr, mat_ptr])
-    dev = torch.from_numpy(packed).to(device)                       # one host -> device copy
-    E = int(edge_ptr[-1])
-    K = len(sizes)
+    packed = torch.from_numpy(np.concatenate([np.concatenate(eis, axis=1).reshape(-1), edge_ptr, seg_ptr, mat_ptr]))
+    if pin and torch.cuda.is_available():
+        packed = packed.pin_memory()
+    return dict(packed=packed, E=int(edge_ptr[-1]), K=len(sizes), sizes=sizes, n_mat=int(mat_ptr[-1]), n_rows=int(seg_ptr[-1]))
+
+
+def hop_distances_launch(host, order='networkx', device=None, non_blocking=False):
+    """Device half: one copy, one launch of `ppk_hop_distances`.  -> (g_flat, sizes, row_order)."""
+    from . import _C
+    if device is None:
+        device = torch.device('cuda')
+    dev = host['packed'].to(device, non_blocking=non_blocking)
+    E, K, sizes = host['E'], host['K'], host['sizes']
     esrc, edst = dev[:E], dev[E:2 * E]
     o = 2 * E
     d_edge_ptr, d_seg_ptr, d_mat_ptr = dev[o:o + K + 1], dev[o + K + 1:o + 2 * K + 2], dev[o + 2 * K + 2:o + 3 * K + 3]
-    g = torch.empty(int(mat_ptr[-1]), dtype=torch.float64, device=device)
-    row_order = torch.empty(int(seg_ptr[-1]), dtype=torch.int64, device=device)
+    g = torch.empty(host['n_mat'], dtype=torch.float64, device=device)
+    row_order = torch.empty(host['n_rows'], dtype=torch.int64, device=device)
     status = torch.zeros(1, dtype=torch.int32, device=device)
     _C.check(_C.lib.ppk_hop_distances(_C.p(esrc) if E else None, _C.p(edst) if E else None, _C.p(d_edge_ptr), _C.p(d_seg_ptr),
                                       _C.p(d_mat_ptr), K, max(sizes), 1 if order == 'networkx' else 0,

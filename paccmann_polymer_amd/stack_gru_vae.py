@@ -18,8 +18,8 @@ K1 sequence kernels + fp32-MFMA GEMMs, K2 cross-entropy, K3 reparameterise+KL,
 each with a hand-written backward wired in through `torch.autograd.Function`.
 
 Restrictions of the HIP path (raise instead of silently falling back):
-`use_stack=True`, `bidirectional=False`, `dropout == 0` in training mode,
-packed batches (`PackedSequence`), fp32.
+`use_stack=True`, `bidirectional=False`, packed batches (`PackedSequence`), fp32.
+Training-mode dropout (`nn.GRU(dropout=p)` between the layers) runs inside the sequence kernels.
 """
 import ctypes
 import os
@@ -254,8 +254,9 @@ def _rowsum_by_token(tokens, V, rows):
     return out
 
 
-def _seq_forward(tokens, batch_sizes, dims, h0, S0, emb, wc, bc, wsi, bsi, gru):
-    """Runs ppk_stackgru_seq_fwd; returns every buffer the backward (or the single-step API) needs."""
+def _seq_forward(tokens, batch_sizes, dims, h0, S0, emb, wc, bc, wsi, bsi, gru, drop=None):
+    """Runs ppk_stackgru_seq_fwd; returns every buffer the backward (or the single-step API) needs.
+    drop: [L-1, NT, Hp] inter-layer dropout factors (0 or 1 / (1 - p)), None outside training-mode dropout."""
     V, E, H, L, W, D, pad = dims
     _C.require_gpu(tokens, h0, emb, wc, bc, wsi, bsi, *gru)
     dev = emb.device
@@ -298,6 +299,13 @@ def _seq_forward(tokens, batch_sizes, dims, h0, S0, emb, wc, bc, wsi, bsi, gru):
     gates = torch.empty(L, NT, 4 * Hp, **f32)
     S = torch.empty(NT, D, W, **f32)
     CS = torch.empty(NT, ldcs, **f32)
+    HD = None
+    if drop is not None and L > 1:
+        if tuple(drop.shape) != (L - 1, NT, Hp) or drop.dtype != torch.float32 or not drop.is_contiguous():
+            raise ValueError()
+        HD = torch.empty(L - 1, NT, Hp, **f32)
+    else:
+        drop = None
     wsb = _lib.ppk_stackgru_seq_fwd_workspace_bytes(B, Hp, L, W)
     ws = _ws(wsb, dev)
     bs_host = batch_sizes.contiguous()
@@ -307,9 +315,9 @@ def _seq_forward(tokens, batch_sizes, dims, h0, S0, emb, wc, bc, wsi, bsi, gru):
         _C.p(tokens), _C.p(table), _C.p(wx0s), ks,
         _ptr_array([dummy] + w_ih_p[1:]), _ptr_array(w_hh_p),
         _ptr_array([dummy] + b_ih_p[1:]), _ptr_array(b_hh_p), _C.p(wcs), _C.p(bcs), _C.p(h0p), _C.p(S0),
-        _C.p(XS), _C.p(Hs), _C.p(HP), _C.p(gates), _C.p(S), _C.p(CS), ldcs,
+        _C.p(XS), _C.p(Hs), _C.p(HP), _C.p(gates), _C.p(S), _C.p(CS), ldcs, _C.p(drop), _C.p(HD),
         _C.p(ws), wsb, _C.stream()))
-    return dict(XS=XS, Hs=Hs, HP=HP, gates=gates, S=S, CS=CS, wcs=wcs, wx0s=wx0s, w_ih_p=w_ih_p, w_hh_p=w_hh_p,
+    return dict(XS=XS, Hs=Hs, HP=HP, gates=gates, S=S, CS=CS, HD=HD, drop=drop, wcs=wcs, wx0s=wx0s, w_ih_p=w_ih_p, w_hh_p=w_hh_p,
                 embc=embc, w0=w0, bs_host=bs_host, dims=(V, E, H, Hp, L, W, D, T, B, NT, ks, ldcs), pad=pad)
 
 
@@ -326,8 +334,8 @@ class _StackGRUSeq(torch.autograd.Function):
     """
 
     @staticmethod
-    def forward(ctx, tokens, batch_sizes, dims, h0, emb, wc, bc, wsi, bsi, *gru):
-        r = _seq_forward(tokens, batch_sizes, dims, h0, None, emb, wc, bc, wsi, bsi, gru)
+    def forward(ctx, tokens, batch_sizes, dims, drop, h0, emb, wc, bc, wsi, bsi, *gru):
+        r = _seq_forward(tokens, batch_sizes, dims, h0, None, emb, wc, bc, wsi, bsi, gru, drop)
         V, E, H, Hp, L, W, D, T, B, NT, ks, ldcs = r['dims']
         f32 = dict(dtype=torch.float32, device=emb.device)
         # transposed copies for the backward's data-gradient GEMMs (k-contiguous operands)
@@ -338,6 +346,7 @@ class _StackGRUSeq(torch.autograd.Function):
         ctx.save_for_backward(tokens, r['XS'], r['Hs'], r['HP'], r['gates'], r['S'], r['CS'], wcs_t, r['embc'], r['w0'],
                               *w_ih_t, *w_hh_t)
         ctx.bs_host = r['bs_host']
+        ctx.drop, ctx.HD = r['drop'], r['HD']                 # inter-layer dropout: factors and the dropped-out inputs of layers >= 1
         ctx.dims = r['dims']
         ctx.padding_idx = -1 if r['pad'] is None else int(r['pad'])
         return _unpad_units(r['Hs'][L - 1], H, Hp, 1)
@@ -364,7 +373,7 @@ class _StackGRUSeq(torch.autograd.Function):
             T, ctypes.c_void_p(ctx.bs_host.data_ptr()), B, NT, Hp, L, W, D,
             _ptr_array(w_ih_t), _ptr_array(w_hh_t), _C.p(wcs_t),
             _C.p(HP), _C.p(gates), _C.p(S), _C.p(CS), ldcs,
-            _C.p(dHtop), _C.p(dXS), ks, _C.p(DGI), _C.p(DGH), _C.p(DCS), _C.p(dh0),
+            _C.p(dHtop), _C.p(dXS), ks, _C.p(DGI), _C.p(DGH), _C.p(DCS), _C.p(dh0), _C.p(ctx.drop),
             _C.p(ws), wsb, st))
 
         # ---- weight gradients: single large TN GEMMs over the saved activations
@@ -415,13 +424,14 @@ class _StackGRUSeq(torch.autograd.Function):
             _unpad_units(dbhh0, H, Hp, 0, 3),
         ]
         for l in range(1, L):
-            dwih, dbih = tn_colsum(DGI[l], 3 * Hp, 3 * Hp, Hs[l - 1], Hp, Hp)
+            below = ctx.HD[l - 1] if ctx.HD is not None else Hs[l - 1]      # what layer l read: h_{l-1} (* its dropout factors)
+            dwih, dbih = tn_colsum(DGI[l], 3 * Hp, 3 * Hp, below, Hp, Hp)
             dwhh, dbhh = tn_colsum(DGH[l], 3 * Hp, 3 * Hp, HP[l], Hp, Hp)
             gru_grads += [w_grad(dwih), w_grad(dwhh), _unpad_units(dbih, H, Hp, 0, 3), _unpad_units(dbhh, H, Hp, 0, 3)]
         dwcs = _unpad_units(tn(DCS, ldcs, 3 + W, HP[L - 1], Hp, Hp), H, Hp, 1)
         dbcs = colsum(DCS, ldcs, 3 + W)
         dh0 = _unpad_units(dh0, H, Hp, 2)
-        return (None, None, None, dh0, demb, dwcs[:3], dbcs[:3], dwcs[3:], dbcs[3:], *gru_grads)
+        return (None, None, None, None, dh0, demb, dwcs[:3], dbcs[:3], dwcs[3:], dbcs[3:], *gru_grads)
 
 
 # --------------------------------------------------------------------------
@@ -478,8 +488,6 @@ class StackGRU(nn.Module):
         """-> top-layer outputs [NT, H] in packed order."""
         if not isinstance(packed, PackedSequence):
             raise TypeError('the HIP path takes PackedSequence batches (batch_mode="packed")')
-        if self.training and self.dropout > 0:
-            raise NotImplementedError('dropout > 0 in training mode is not implemented in the HIP path')
         dev = self.embedding.weight.device
         tokens = packed.data
         # ids index a [V, 3H] table inside the kernels: validate like nn.Embedding does (IndexError), on the host copy
@@ -495,11 +503,36 @@ class StackGRU(nn.Module):
             tokens = tokens.reshape(-1)
         tokens = tokens.to(device=dev, dtype=torch.int64).contiguous()
         bs = packed.batch_sizes.to('cpu', torch.int64)
-        return _StackGRUSeq.apply(tokens, bs, self._dims(), h0, self.embedding.weight,
+        drop = self._dropout_factors(int(tokens.numel()), dev)
+        return _StackGRUSeq.apply(tokens, bs, self._dims(), drop, h0, self.embedding.weight,
                                   self.stack_controls_layer.weight, self.stack_controls_layer.bias,
                                   self.stack_input_layer.weight, self.stack_input_layer.bias,
                                   *self._gru_params())
 
+
+    # Training-mode dropout of nn.GRU(dropout = p): between the layers, fresh factors at every timestep (upstream calls
+    # nn.GRU with seq_len 1 per step).  `drop_factors_fn(n_masked_layers, NT, H) -> [n, NT, H]` injects the factors in
+    # packed-row order (parity tests: the CPU oracle cannot share the device's noise, SURVEY landmine 10); otherwise
+    # they come from Philox keyed by (seed, layer, packed row, unit) with the seed drawn from torch's CPU generator,
+    # so `torch.manual_seed` makes a run repeatable and the mask does not depend on the launch schedule.
+    drop_factors_fn = None
+
+    def _dropout_factors(self, NT, dev):
+        if not (self.training and self.dropout > 0 and self.n_layers > 1):
+            return None
+        H, L = self.rnn_cell_size, self.n_layers
+        Hp = _round_up(H, 32)
+        if self.drop_factors_fn is not None:
+            f = self.drop_factors_fn(L - 1, NT, H).to(device=dev, dtype=torch.float32)
+            if tuple(f.shape) != (L - 1, NT, H):
+                raise ValueError()
+            return _pad_units(f, H, Hp, 2)
+        if not 0.0 < self.dropout < 1.0:
+            raise ValueError('dropout must lie in [0, 1)')
+        out = torch.empty(L - 1, NT, Hp, dtype=torch.float32, device=dev)
+        seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+        _C.check(_lib.ppk_dropout_factors(seed, float(self.dropout), L - 1, NT, Hp, H, _C.p(out), _C.stream()))
+        return out
 
     def init_state(self, batch_size: Optional[int] = None):
         """Zero hidden state [L, B, H] and empty stack [B, D, W] (upstream `init_hidden` / `init_stack`)."""

@@ -15,7 +15,8 @@ from typing import Optional, Sequence
 import numpy as np
 import torch
 
-from .data_prep import hop_distance_matrices_device, hop_distance_matrix, packed_sequential_data_preparation
+from .data_prep import (hop_distance_matrices_device, hop_distance_matrix, hop_distances_launch, hop_inputs_host,
+                        packed_preparation_host, packed_preparation_to_device, packed_sequential_data_preparation)
 from .graph_constrained_loss import graph_loss, graph_loss_segmented
 from .paccmann_encoder import get_device
 
@@ -95,6 +96,84 @@ def train(epoch, model, train_loader, optimizer, scheduler, graph_gamma, growth_
     logger.info(f"Learning rate {optimizer.param_groups[0]['lr']}\tkl_scale {kl_scale}")
     logger.info(f'{epoch}\t{train_loss / max(_iter, 1)}\t{time() - start_time}')
     return train_loss / max(_iter + 1, 1)
+
+
+def _bundle_groups(train_loader, bundles_per_step):
+    group = []
+    for data in train_loader:
+        group.append(data)
+        if len(group) == bundles_per_step:
+            yield group
+            group = []
+    if group:
+        yield group
+
+
+def _prepare_group_host(group):
+    """Everything of one optimizer step that is host work (runs on the worker thread): packing index arithmetic of
+    all SMILES of the group's bundles (reference utils.py:35-98) and the flat edge arrays of its hop-distance
+    matrices (reactions_vae.py:79-83), in page-locked memory so the copies are asynchronous."""
+    seqs = [s for data in group for s in data.x]
+    sizes = [len(data.x) for data in group]
+    if max(sizes) > 64:
+        raise ValueError('train_bundled: bundles of at most 64 SMILES (the reference samples <= 21, utils.py:156-196)')
+    packed = packed_preparation_host(seqs, pin=True)
+    hops = hop_inputs_host([data.edge_index for data in group], sizes, pin=True)
+    return packed, hops, len(seqs)
+
+
+def train_bundled(epoch, model, train_loader, optimizer, scheduler, graph_gamma, bundles_per_step=128, growth_rate=0.0015,
+                  writer=None, verbose=False, distance_order='networkx', use_kl=False, grad_sync=None):
+    """Epoch driver of the batched scale-up (BASELINE configs[1] / [4]): the reference loader's bundles
+    (`Data(x = list of token tensors, edge_index)`, reactions_vae.py:52-59) are taken `bundles_per_step` at a time
+    and each group is ONE optimizer step of `train_step_bundles` — decoder loss over all its SMILES + gamma * the sum
+    of the per-bundle graph losses, i.e. `bundles_per_step` reference steps with gradient accumulation.  With
+    bundles_per_step == 1 it is the reference's loop (`train`).
+
+    Host / device overlap (after the kernels, host Python is the critical path): a worker thread
+    packs group t + 1 and builds its hop-matrix inputs into pinned buffers while the GPU runs group t; the main
+    thread only issues asynchronous copies and launches.  Nothing inside the epoch reads the device: the three loss
+    scalars of every step stay there and are read once at the end (the writer gets the same values, later).
+    Returns the mean loss per step like `train`."""
+    from concurrent.futures import ThreadPoolExecutor
+    start_time = time()
+    device = get_device()
+    model.gru_vae.to(device)
+    model.gru_vae.train()
+    history = []
+    groups = _bundle_groups(train_loader, int(bundles_per_step))
+    n_iter = max(1, -(-len(train_loader) // int(bundles_per_step))) if hasattr(train_loader, '__len__') else 1
+    kl_scale = 0.0
+    with ThreadPoolExecutor(max_workers=1) as pool:
+        nxt = next(groups, None)
+        pending = pool.submit(_prepare_group_host, nxt) if nxt is not None else None
+        _iter = 0
+        while pending is not None:
+            packed, hops, batch_size = pending.result()
+            nxt = next(groups, None)
+            pending = pool.submit(_prepare_group_host, nxt) if nxt is not None else None       # overlaps this step's GPU work
+            model.gru_decoder._update_batch_size(batch_size)
+            model.gru_encoder._update_batch_size(batch_size)
+            encoder_seq, decoder_seq, target_seq = packed_preparation_to_device(packed, device, non_blocking=True)
+            g_flat, sizes, _ = hop_distances_launch(hops, distance_order, device, non_blocking=True)
+            kl_scale = kl_schedule(epoch, _iter, n_iter, growth_rate)
+            loss, decoder_loss, gr_loss = train_step_bundles(model, optimizer, encoder_seq, decoder_seq, target_seq, g_flat, sizes,
+                                                             graph_gamma, use_kl=use_kl, kl_scale=kl_scale, grad_sync=grad_sync)
+            history.append(torch.stack([decoder_loss.reshape(()), gr_loss.reshape(()), loss.reshape(())]))
+            _iter += 1
+    values = torch.stack(history).cpu().tolist() if history else []          # the epoch's only device-to-host read
+    if writer is not None:
+        for i, (dl, gl, l) in enumerate(values):
+            step = i + epoch * n_iter
+            writer.add_scalar('recon_loss', dl, step)
+            writer.add_scalar('graph_loss', gl, step)
+            writer.add_scalar('loss', l, step)
+    train_loss = sum(v[2] for v in values)
+    if scheduler is not None:
+        scheduler.step()
+    logger.info(f"Learning rate {optimizer.param_groups[0]['lr']}\tkl_scale {kl_scale}")
+    logger.info(f'{epoch}\t{train_loss / max(len(values), 1)}\t{time() - start_time}')
+    return train_loss / max(len(values), 1)
 
 
 def export_latents(model, pairs: Sequence[Sequence[torch.Tensor]], device=None, pairs_per_call: int = 2048):

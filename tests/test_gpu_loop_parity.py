@@ -372,3 +372,84 @@ def test_max_normaliser_ties_split_evenly_dense_and_sparse(copies):
     ls.backward()
     assert abs(float(ls.detach()) - float(ref.detach())) <= 1e-5 * abs(float(ref.detach()))
     assert rel(zs.grad, torch.tensor(dref)) <= 1e-4
+
+
+def _feed_eps(model, eps_list):
+    feed = iter(eps_list)
+    orig = model.gru_vae.reparameterize
+    model.gru_vae.reparameterize = lambda mu, lv, eps=None: orig(mu, lv, next(feed).float().cuda())
+
+
+def test_train_bundled_one_bundle_per_step_reproduces_train():
+    """trainer.train_bundled with bundles_per_step = 1 IS the reference loop (reactions_vae.py:52-96): same
+    parameters after two epochs as trainer.train on the same bundles and noise, same scalars to the writer."""
+    from paccmann_polymer_amd.optim import FlatAdam
+    from paccmann_polymer_amd.trainer import train, train_bundled
+    rng = np.random.default_rng(31)
+    loader = [make_bundle(rng, int(n), SMALL['vocab_size'], 4, 12) for n in (5, 9, 3, 16)]
+    eps = [torch.tensor(rng.standard_normal((len(b.x), SMALL['latent_dim']))) for _ in range(2) for b in loader]
+
+    class Writer:
+        def __init__(self):
+            self.rows = {}
+
+        def add_scalar(self, tag, value, step):
+            self.rows.setdefault(tag, {})[step] = value
+    out = []
+    for fn in (train, train_bundled):
+        _, model = build_pair(SMALL, 31)
+        opt = FlatAdam(model.gru_vae.parameters(), lr=2e-3)
+        _feed_eps(model, eps)
+        w = Writer()
+        for e in range(2):
+            if fn is train:
+                train(e, model, loader, opt, None, graph_gamma=0.3, writer=w)
+            else:
+                train_bundled(e, model, loader, opt, None, graph_gamma=0.3, bundles_per_step=1, writer=w)
+        out.append((w.rows, {k: p.detach().clone() for k, p in model.gru_vae.named_parameters()}))
+    (rows_a, pa), (rows_b, pb) = out
+    for tag in ('recon_loss', 'graph_loss', 'loss'):
+        assert sorted(rows_a[tag]) == sorted(rows_b[tag]) == list(range(8))
+        for i in range(8):
+            assert abs(rows_a[tag][i] - rows_b[tag][i]) <= 1e-6 * abs(rows_a[tag][i]), (tag, i)
+    for k in pa:
+        assert float((pa[k] - pb[k]).abs().max()) <= 1e-6 * max(float(pa[k].abs().max()), 1e-12), k
+
+
+def test_train_bundled_groups_of_four_match_oracle_loop():
+    """bundles_per_step = 4 over 10 bundles (groups of 4, 4 and a ragged last group of 2), two epochs with StepLR, against
+    the oracle's batched step + torch.optim.Adam; the worker thread prepares group t + 1 while group t runs."""
+    from paccmann_polymer_amd.optim import FlatAdam
+    from paccmann_polymer_amd.trainer import train_bundled
+    rng = np.random.default_rng(32)
+    ref, model = build_pair(SMALL, 32)
+    start = {k: v.detach().clone() for k, v in ref.named_parameters()}
+    loader = [make_bundle(rng, int(rng.integers(3, 17)), SMALL['vocab_size'], 3, 14) for _ in range(10)]
+    groups = [loader[0:4], loader[4:8], loader[8:10]]
+    gamma, lr, epochs = 0.5, 1e-3, 2
+    eps = [torch.tensor(rng.standard_normal((sum(len(b.x) for b in g), SMALL['latent_dim']))) for _ in range(epochs) for g in groups]
+    opt_r = torch.optim.Adam(ref.parameters(), lr=lr)
+    sch_r = torch.optim.lr_scheduler.StepLR(opt_r, 1, gamma=0.5)
+    want = []
+    it = iter(eps)
+    for e in range(epochs):
+        for g in groups:
+            want.append(oracle_step(ref, opt_r, g, next(it), gamma))
+        sch_r.step()
+    opt = FlatAdam(model.gru_vae.parameters(), lr=lr)
+    sch = torch.optim.lr_scheduler.StepLR(opt, 1, gamma=0.5)
+    _feed_eps(model, eps)
+
+    class Writer:
+        rows = {}
+
+        def add_scalar(self, tag, value, step):
+            self.rows.setdefault(tag, {})[step] = value
+    w = Writer()
+    for e in range(epochs):
+        train_bundled(e, model, loader, opt, sch, graph_gamma=gamma, bundles_per_step=4, writer=w)
+    assert opt.param_groups[0]['lr'] == pytest.approx(lr * 0.25)
+    for i, (dl, gl) in enumerate(want):
+        assert abs(w.rows['recon_loss'][i] - dl) <= 1e-4 * abs(dl), (i, w.rows['recon_loss'][i], dl)
+        assert abs(w.rows['graph_loss'][i] - gl) <= 1e-4 * abs(gl), (i, w.rows['graph_loss'][i], gl)
+    assert_params_track(model, ref, start, 'train_bundled')

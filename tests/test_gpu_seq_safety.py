@@ -75,7 +75,7 @@ def _seq_fwd_raw(lib, _C, T, bs, B, NT, V, H, L, W, D, tokens, table, wx0s, ks, 
     _C.check(lib.ppk_stackgru_seq_fwd(
         T, ctypes.c_void_p(bs_host.data_ptr()), B, NT, V, H, L, W, D,
         _C.p(tokens), _C.p(table), _C.p(wx0s), ks, arr(w_ih), arr(w_hh), arr(b_ih), arr(b_hh), _C.p(wcs), _C.p(bcs), _C.p(h0), None,
-        _C.p(XS), _C.p(Hs), _C.p(HP), _C.p(gates), _C.p(S), _C.p(CS), ldcs, _C.p(ws), wsb, _C.stream()))
+        _C.p(XS), _C.p(Hs), _C.p(HP), _C.p(gates), _C.p(S), _C.p(CS), ldcs, None, None, _C.p(ws), wsb, _C.stream()))
     torch.cuda.synchronize()
     assert bool((ws[wsb:] == 0xA5).all()), 'the entry point wrote past the workspace it asked for'
     return Hs, S, CS, XS

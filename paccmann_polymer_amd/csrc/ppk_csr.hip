@@ -41,15 +41,45 @@ inline unsigned grid_for(long long work, unsigned cap = 8192)
     return (unsigned)(b < cap ? b : cap);
 }
 
+// Block-level aggregation of same-target edges before they touch global memory.  On a power-law graph a third of the
+// edges can point at a handful of hubs: 1.7 M global atomics on 3 addresses serialise (the 3-hub graph of configs[2]
+// took 35 ms to build, nearly all of it in k_count / k_fill).  Each block of 256 edges first groups its targets in an
+// LDS hash table (LDS atomics: a few cycles each), then issues ONE global atomic per distinct target.
+constexpr int AGG_SLOTS = 512;                   // >= 2 x 256 distinct keys: linear probing always terminates
+struct AggTable { int key[AGG_SLOTS]; int cnt[AGG_SLOTS]; int base[AGG_SLOTS]; };
+__device__ __forceinline__ void agg_clear(AggTable& t)
+{
+    for (int s = threadIdx.x; s < AGG_SLOTS; s += 256) { t.key[s] = -1; t.cnt[s] = 0; }
+}
+// slot of key d (inserted if new); returns this lane's rank among the block's lanes with the same key
+__device__ __forceinline__ int agg_insert(AggTable& t, int d, int& slot)
+{
+    slot = (int)(((unsigned)d * 2654435761u) >> 23) & (AGG_SLOTS - 1);
+    for (;;) {
+        const int old = atomicCAS(&t.key[slot], -1, d);
+        if (old == -1 || old == d) break;
+        slot = (slot + 1) & (AGG_SLOTS - 1);
+    }
+    return atomicAdd(&t.cnt[slot], 1);
+}
+
 // cnt[target] += 1 for every non-self-loop edge (integer atomics: order-independent result)
 __global__ __launch_bounds__(256) void k_count(const int64_t* __restrict__ src, const int64_t* __restrict__ dst, long long E,
                                                long long N, long long NS, int drop_self_loops, int* __restrict__ cnt, int* __restrict__ bad)
 {
-    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < E; e += (long long)gridDim.x * 256) {
-        const long long s = src[e], d = dst[e];
-        if (s < 0 || s >= NS || d < 0 || d >= N) { atomicOr(bad, 1); continue; }
-        if (drop_self_loops && s == d) continue;
-        atomicAdd(&cnt[d], 1);
+    __shared__ AggTable t;
+    for (long long e0 = (long long)blockIdx.x * 256; e0 < E; e0 += (long long)gridDim.x * 256) {      // block-uniform trip count
+        agg_clear(t);
+        __syncthreads();
+        const long long e = e0 + threadIdx.x;
+        if (e < E) {
+            const long long s = src[e], d = dst[e];
+            if (s < 0 || s >= NS || d < 0 || d >= N) atomicOr(bad, 1);
+            else if (!(drop_self_loops && s == d)) { int slot; agg_insert(t, (int)d, slot); }
+        }
+        __syncthreads();
+        for (int s = threadIdx.x; s < AGG_SLOTS; s += 256) if (t.key[s] >= 0) atomicAdd(&cnt[t.key[s]], t.cnt[s]);
+        __syncthreads();
     }
 }
 
@@ -122,25 +152,35 @@ __global__ __launch_bounds__(256) void k_scan_add(long long* __restrict__ rowptr
     if (i == N) rowptr[N] = *total;
 }
 
-// fill: arbitrary position inside the row; the self loop gets edge id E + i (sorts last)
+// fill: arbitrary position inside the row; the self loop gets edge id E + i (sorts last).  Same block-level grouping
+// as k_count: one global cursor atomic per distinct target of the block, positions handed out from the LDS ranks.
 __global__ __launch_bounds__(256) void k_fill(const int64_t* __restrict__ src, const int64_t* __restrict__ dst, long long E,
                                               long long N, long long NS, int drop_self_loops, int add_self_loops,
                                               const long long* __restrict__ rowptr, int* __restrict__ cursor,
                                               long long* __restrict__ eid)
 {
+    __shared__ AggTable t;
     const long long total = E + (add_self_loops ? N : 0);
-    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
-        long long d;
+    for (long long e0 = (long long)blockIdx.x * 256; e0 < total; e0 += (long long)gridDim.x * 256) {  // block-uniform trip count
+        agg_clear(t);
+        __syncthreads();
+        const long long e = e0 + threadIdx.x;
+        long long d = -1;
         if (e < E) {
             const long long s = src[e];
             d = dst[e];
-            if (s < 0 || s >= NS || d < 0 || d >= N) continue;
-            if (drop_self_loops && s == d) continue;
-        } else {
+            if (s < 0 || s >= NS || d < 0 || d >= N) d = -1;
+            else if (drop_self_loops && s == d) d = -1;
+        } else if (e < total) {
             d = e - E;
         }
-        const int pos = atomicAdd(&cursor[d], 1);
-        eid[rowptr[d] + pos] = e;
+        int slot = 0, rank = 0;
+        if (d >= 0) rank = agg_insert(t, (int)d, slot);
+        __syncthreads();
+        for (int s = threadIdx.x; s < AGG_SLOTS; s += 256) if (t.key[s] >= 0) t.base[s] = atomicAdd(&cursor[t.key[s]], t.cnt[s]);
+        __syncthreads();
+        if (d >= 0) eid[rowptr[d] + t.base[slot] + rank] = e;
+        __syncthreads();
     }
 }
 
@@ -202,9 +242,23 @@ __global__ __launch_bounds__(256) void k_sort_long(const long long* __restrict__
         const long long i = long_rows[q];
         const long long b = rowptr[i];
         const long long len = rowptr[i + 1] - b;
-        for (long long c0 = 0; c0 < len; c0 += LDS_SORT_MAX)
+        if (len <= LDS_SORT_MAX) lds_sort(buf, eid + b, (int)len);
+        else if (threadIdx.x == 0) vlong_rows[atomicAdd(n_vlong, 1)] = (int)i;       // k_sort_vlong_chunks + merge passes
+    }
+}
+// rows beyond one LDS image: every LDS_SORT_MAX-entry chunk is sorted by its own workgroup (grid.x over the chunks of a
+// row, grid.y over the queued rows).  One workgroup per ROW walked a 5.5e5-entry hub's 68 chunks one after the other:
+// 11 ms of the 14 ms that the 3-hub graph of configs[2] took to build.
+__global__ __launch_bounds__(256) void k_sort_vlong_chunks(const long long* __restrict__ rowptr, long long* __restrict__ eid,
+                                                           const int* __restrict__ vlong_rows, const int* __restrict__ n_vlong)
+{
+    __shared__ long long buf[LDS_SORT_MAX];
+    const int nv = *n_vlong;
+    for (int q = blockIdx.y; q < nv; q += gridDim.y) {
+        const long long i = vlong_rows[q];
+        const long long b = rowptr[i], len = rowptr[i + 1] - b;
+        for (long long c0 = (long long)blockIdx.x * LDS_SORT_MAX; c0 < len; c0 += (long long)gridDim.x * LDS_SORT_MAX)
             lds_sort(buf, eid + b + c0, (int)(len - c0 < LDS_SORT_MAX ? len - c0 : LDS_SORT_MAX));
-        if (len > LDS_SORT_MAX && threadIdx.x == 0) vlong_rows[atomicAdd(n_vlong, 1)] = (int)i;
     }
 }
 // merge pass p over the queued rows: sorted runs of LDS_SORT_MAX << p entries are merged in pairs.  Every entry
@@ -564,6 +618,10 @@ int ppk_csr_build_rect(const int64_t* src, const int64_t* dst, int64_t E, int64_
     int* n_vlong = w.n_long + 1;
     k_sort_long<<<dim3(512), dim3(256), 0, stream>>>((const long long*)rowptr, (long long*)eid, w.long_rows, w.n_long, vlong_rows, n_vlong);
     PPK_CHECK_LAUNCH("k_sort_long");
+    if (E + 1 > LDS_SORT_MAX) {
+        k_sort_vlong_chunks<<<dim3(128, 16), dim3(256), 0, stream>>>((const long long*)rowptr, (long long*)eid, vlong_rows, n_vlong);
+        PPK_CHECK_LAUNCH("k_sort_vlong_chunks");
+    }
     int passes = 0;                                   // a row holds at most E + 1 entries
     while (((long long)LDS_SORT_MAX << passes) < E + 1) ++passes;
     for (int p = 0; p < passes; ++p) {

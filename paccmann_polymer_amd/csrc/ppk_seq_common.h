@@ -19,12 +19,27 @@ constexpr int EPI_LD = 32;                     // floats per transposed accumula
                                                // every 16-lane read group covers 256 contiguous bytes without padding
 constexpr int EPI_TILE = 32 * EPI_LD;
 #ifndef PPK_SPIN_LIMIT
-#define PPK_SPIN_LIMIT (1 << 19)
+#define PPK_SPIN_LIMIT (1 << 21)
 #endif
-constexpr int SPIN_LIMIT = PPK_SPIN_LIMIT;     // polls ~3.4 us apart (PPK_POLL_SLEEP): ~2 s, then the status word is set, every workgroup
+constexpr int SPIN_LIMIT = PPK_SPIN_LIMIT;     // polls ~1.5 us apart (PPK_POLL_SLEEP + the load): ~3 s, then the status word is set, every workgroup
                                                // leaves at its next wait and k_seq_poison turns every output of the launch into NaN
                                                // (libppk_spin.so, built with -DPPK_SPIN_LIMIT=1, forces that path: tests/test_gpu_stackgru.py)
 #define PPK_LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
+// ints between two group counters: every (group, phase) counter sits on a line of its own, so that the polls of one
+// group's consumers do not queue with the adds and polls of the other groups (32 groups x 3 counters were 4 lines)
+#ifndef PPK_CTR_STRIDE
+#define PPK_CTR_STRIDE 1024
+#endif
+constexpr int CTR_STRIDE = PPK_CTR_STRIDE;
+// cache policy of the LDS-DMA loads of HANDED-OFF operands (hidden rows, stack tops, gate gradients, DCS rows):
+// PPK_NO_ACQUIRE: sc1 (L1-bypassing) loads on every handed-off byte replace the agent acquire after the poll
+// (MI355X_MICROARCH.md, Valid forms: every such byte is stored sc1, every storing wave drains vmcnt, one lane signals
+// behind a workgroup barrier, the polling wave's workgroup barrier precedes every load)
+#ifdef PPK_NO_ACQUIRE
+constexpr int DMA_AUX_HANDOFF = 16;
+#else
+constexpr int DMA_AUX_HANDOFF = 0;
+#endif
 
 template <int N> __device__ __forceinline__ void wait_vmcnt()
 {
@@ -59,11 +74,13 @@ __device__ __forceinline__ void group_signal(int* ctr)
     if (threadIdx.x == 0) __hip_atomic_fetch_add(ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 // one lane polls, acquires, then the workgroup barrier; false = timeout / another workgroup gave up
-// cycles / 64 between two polls of a group counter.  Same-box ABBA runs at batch 2048 (tools/ab_bench.sh), k_seq_bwd ms:
-// 1: 20.65, 8: 20.13, 24: 19.56, 64: 19.12, 127: 18.70, 254: 19.16, back-off 8..127: 19.27 — every poll is an agent-scope
-// load on a word that the group's producers are about to add to, and it queues with the neighbour's streaming
+// cycles / 64 between two polls of a group counter.  Round 2 kept all counters back to back (32 groups x 3 words = 4 lines):
+// every poll queued with every other group's polls and adds on those lines, and the best interval was 127 (k_seq_bwd
+// 20.65 / 20.13 / 19.56 / 19.12 / 18.70 / 19.16 ms at 1 / 8 / 24 / 64 / 127 / 254).  With every counter on a line of its own
+// (PPK_CTR_STRIDE, 4 KB apart) the interval no longer matters (same-box runs, profiles/r03_handoff_ab.txt: k_seq_bwd
+// 18.7 -> 17.9 ms from the padding alone, 17.75 at intervals 32 and 8); 32 is kept.
 #ifndef PPK_POLL_SLEEP
-#define PPK_POLL_SLEEP 127
+#define PPK_POLL_SLEEP 32
 #endif
 __device__ __forceinline__ bool group_wait(int* ctr, int target, int* status, volatile int* flag)
 {
@@ -88,8 +105,10 @@ __device__ __forceinline__ bool group_wait(int* ctr, int target, int* status, vo
 #endif
         }
         if (!ok) __hip_atomic_store(status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#ifndef PPK_NO_ACQUIRE
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
         *flag = ok;
     }
     __syncthreads();

@@ -102,8 +102,8 @@ __device__ __forceinline__ void kloop(float* lds, const float* s0, const float* 
         return;
 #endif
         float* base = lds + buf * SB + wave * 256;
-        __builtin_amdgcn_global_load_lds(s0, PPK_LDS_PTR(base), 16, 0, 0); s0 += BK;
-        if constexpr (NA == 2) { __builtin_amdgcn_global_load_lds(s1, PPK_LDS_PTR(base + 1024), 16, 0, 0); s1 += BK; }
+        __builtin_amdgcn_global_load_lds(s0, PPK_LDS_PTR(base), 16, 0, DMA_AUX_HANDOFF); s0 += BK;
+        if constexpr (NA == 2) { __builtin_amdgcn_global_load_lds(s1, PPK_LDS_PTR(base + 1024), 16, 0, DMA_AUX_HANDOFF); s1 += BK; }
         __builtin_amdgcn_global_load_lds(s2, PPK_LDS_PTR(base + NA * 1024), 16, 0, 0); s2 += BK;
         __builtin_amdgcn_global_load_lds(s3, PPK_LDS_PTR(base + (NA + 1) * 1024), 16, 0, 0); s3 += BK;
         __builtin_amdgcn_global_load_lds(s4, PPK_LDS_PTR(base + (NA + 2) * 1024), 16, 0, 0); s4 += BK;
@@ -252,8 +252,8 @@ __device__ __forceinline__ bool cell(const SeqArgs& a, float* lds, volatile int*
     }
     TSTAMP(0);
     // the input of this layer at this step: the stack top (layer 0) or the layer below
-    int* ctr = a.ctr + (long long)g * (a.L + 1);
-    if (!group_wait(l == 0 ? ctr + a.L : ctr + (l - 1), a.ntiles * (t + 1), a.status, flag)) return false;
+    int* ctr = a.ctr + (long long)g * (a.L + 1) * CTR_STRIDE;
+    if (!group_wait(l == 0 ? ctr + a.L * CTR_STRIDE : ctr + (l - 1) * CTR_STRIDE, a.ntiles * (t + 1), a.status, flag)) return false;
     TSTAMP(1);
     // part B: W_ih[l] . x_l(t)
     {
@@ -330,7 +330,7 @@ __device__ __forceinline__ bool cell(const SeqArgs& a, float* lds, volatile int*
     TSTAMP(13);
     if (l == a.L - 1) heads_partial(heads_ctx(a, g, j, st.n[0], NA == 2 ? st.n[1] : 0), hout[0], hout[1]);
     TSTAMP(3);
-    group_signal(ctr + l);
+    group_signal(ctr + l * CTR_STRIDE);
     TSTAMP(4);
     return true;
 }
@@ -510,7 +510,7 @@ __device__ __noinline__ bool stack_phase(StackCtx c)
 __device__ __forceinline__ StackCtx stack_ctx(const SeqArgs& a, const int* r0, const int* off, int t, int g, int j)
 {
     StackCtx c;
-    c.wctr = a.ctr + (long long)g * (a.L + 1) + (a.L - 1); c.status = a.status; c.wtarget = a.ntiles * (t + 1);      // + the "step -1" signal
+    c.wctr = a.ctr + ((long long)g * (a.L + 1) + (a.L - 1)) * CTR_STRIDE; c.status = a.status; c.wtarget = a.ntiles * (t + 1);      // + the "step -1" signal
     const long long DW = (long long)a.D * a.W, ot = off[t], op = t > 0 ? off[t - 1] : 0;
     c.hpart_g = a.hpart + (long long)g * a.ntiles * 64 * a.ldcs;
     c.bcs = a.bcs;
@@ -570,7 +570,7 @@ __global__ __launch_bounds__(256, 2) void k_seq_fwd(const SeqArgs a)
     __syncthreads();
     const int m0 = a.pair ? 2 * g : g, m1 = a.pair ? 2 * g + 1 : 2 * a.G - 1 - g;
     const int r0[2] = {32 * m0, m1 < a.MT && m1 != m0 ? 32 * m1 : -1};
-    int* ctr = a.ctr + (long long)g * (a.L + 1);
+    int* ctr = a.ctr + (long long)g * (a.L + 1) * CTR_STRIDE;
 
     // "step -1": the heads of the initial hidden state of the top layer
     {
@@ -585,9 +585,9 @@ __global__ __launch_bounds__(256, 2) void k_seq_fwd(const SeqArgs a)
         }
         heads_partial(heads_ctx(a, g, j, n0[0], n0[1]), hv[0], hv[1]);
     }
-    group_signal(ctr + (a.L - 1));
+    group_signal(ctr + (a.L - 1) * CTR_STRIDE);
     if (!stack_phase(stack_ctx(a, r0, off, 0, g, j))) return;      // a hand-off never arrived (status word set; k_seq_poison makes it visible in every output)
-    group_signal(ctr + a.L);
+    group_signal(ctr + a.L * CTR_STRIDE);
     for (int t = 0; t < a.T; ++t) {
         const int bt = a.bs[t];
         if (bt <= r0[0]) break;
@@ -607,7 +607,7 @@ __global__ __launch_bounds__(256, 2) void k_seq_fwd(const SeqArgs a)
         if (t + 1 < a.T && a.bs[t + 1] > r0[0]) {
             if (!stack_phase(stack_ctx(a, r0, off, t + 1, g, j))) return;      // a hand-off never arrived (status word set; k_seq_poison makes it visible in every output)
             TSTAMP(6);
-            group_signal(ctr + a.L);
+            group_signal(ctr + a.L * CTR_STRIDE);
             TSTAMP(7);
         }
     }
@@ -747,7 +747,7 @@ size_t seq_fwd_persist_ws_bytes(int64_t B, int64_t H, int64_t L, int64_t W)
 {
     const int64_t ldcs = (3 + W + 31) / 32 * 32;
     const int64_t G = ((B + 31) / 32 + 1) / 2;
-    return ppk_align_up(sizeof(float) * (size_t)H * (size_t)ldcs, 256) + ppk_align_up(sizeof(int) * (size_t)(G * (L + 1) + 64), 256)
+    return ppk_align_up(sizeof(float) * (size_t)H * (size_t)ldcs, 256) + ppk_align_up(sizeof(int) * (size_t)(G * (L + 1) * CTR_STRIDE + 64), 256)
            + ppk_align_up(sizeof(float) * (size_t)G * (size_t)(H / 32) * 64 * (size_t)ldcs, 256);
 }
 
@@ -777,9 +777,9 @@ int seq_fwd_persist(int64_t T, const int64_t* bs, int64_t B, int64_t NT, int64_t
     for (int t = 0; t < (int)T; ++t) a.bs[t] = (int)bs[t];
     char* cur = (char*)ws;
     float* wcs_t = (float*)ppk_carve(cur, sizeof(float) * (size_t)H * (size_t)ldcs);
-    const size_t nctr = (size_t)a.G * (size_t)(L + 1) + 64;
+    const size_t nctr = (size_t)a.G * (size_t)(L + 1) * CTR_STRIDE + 64;
     int* ctr = (int*)ppk_carve(cur, sizeof(int) * nctr);
-    a.wcs_t = wcs_t; a.ctr = ctr; a.status = ctr + (size_t)a.G * (size_t)(L + 1);
+    a.wcs_t = wcs_t; a.ctr = ctr; a.status = ctr + (size_t)a.G * (size_t)(L + 1) * CTR_STRIDE;
     a.hpart = (float*)ppk_carve(cur, sizeof(float) * (size_t)a.G * (size_t)a.ntiles * 64 * (size_t)ldcs);
     {
         const int64_t DW4 = (D * W + 3) / 4 * 4;

@@ -106,11 +106,11 @@ __device__ __forceinline__ void kloop2(float* lds, const float* x0, const float*
         return;
 #endif
         float* base = lds + buf * SB + wave * 256;
-        __builtin_amdgcn_global_load_lds(x0, PPK_LDS_PTR(base), 16, 0, 0); x0 += adv;
-        if constexpr (NA == 2) { __builtin_amdgcn_global_load_lds(x1, PPK_LDS_PTR(base + 1024), 16, 0, 0); x1 += adv; }
+        __builtin_amdgcn_global_load_lds(x0, PPK_LDS_PTR(base), 16, 0, DMA_AUX_HANDOFF); x0 += adv;
+        if constexpr (NA == 2) { __builtin_amdgcn_global_load_lds(x1, PPK_LDS_PTR(base + 1024), 16, 0, DMA_AUX_HANDOFF); x1 += adv; }
         if constexpr (!SHARE) {
-            __builtin_amdgcn_global_load_lds(y0, PPK_LDS_PTR(base + OY), 16, 0, 0); y0 += adv;
-            if constexpr (NA == 2) { __builtin_amdgcn_global_load_lds(y1, PPK_LDS_PTR(base + OY + 1024), 16, 0, 0); y1 += adv; }
+            __builtin_amdgcn_global_load_lds(y0, PPK_LDS_PTR(base + OY), 16, 0, DMA_AUX_HANDOFF); y0 += adv;
+            if constexpr (NA == 2) { __builtin_amdgcn_global_load_lds(y1, PPK_LDS_PTR(base + OY + 1024), 16, 0, DMA_AUX_HANDOFF); y1 += adv; }
         }
         __builtin_amdgcn_global_load_lds(bx, PPK_LDS_PTR(base + OB), 16, 0, 0); bx += adv;
         __builtin_amdgcn_global_load_lds(by, PPK_LDS_PTR(base + OB + 1024), 16, 0, 0); by += adv;
@@ -168,8 +168,8 @@ __device__ __forceinline__ void kloop1(float* lds, const float* x0, const float*
         return;
 #endif
         float* base = lds + buf * STG_BUF + wave * 256;
-        __builtin_amdgcn_global_load_lds(x0, PPK_LDS_PTR(base), 16, 0, 0); x0 += BK;
-        if constexpr (NA == 2) { __builtin_amdgcn_global_load_lds(x1, PPK_LDS_PTR(base + 1024), 16, 0, 0); x1 += BK; }
+        __builtin_amdgcn_global_load_lds(x0, PPK_LDS_PTR(base), 16, 0, DMA_AUX_HANDOFF); x0 += BK;
+        if constexpr (NA == 2) { __builtin_amdgcn_global_load_lds(x1, PPK_LDS_PTR(base + 1024), 16, 0, DMA_AUX_HANDOFF); x1 += BK; }
         __builtin_amdgcn_global_load_lds(bx, PPK_LDS_PTR(base + 4096), 16, 0, 0); bx += BK;
     };
     __syncthreads();
@@ -561,14 +561,14 @@ __device__ __forceinline__ bool step_bwd(const BwdArgs& a, float* lds, const int
     const int li = lane & 31, hh = lane >> 5;
     const int tid = threadIdx.x, er = tid >> 3, c4 = (tid & 7) * 4, u = 32 * j + c4;
     const int ub = 32 * j + i;                        // weight row of this lane's DMA piece
-    int* ctr = a.ctr + (long long)g * (L + 1);
+    int* ctr = a.ctr + (long long)g * (L + 1) * CTR_STRIDE;
     f32x16 accD[2], accC[2];
     f32x4 d0[2][3];                                   // dgi of layer 0 of this thread's cells (for the dXS partial)
 
     // ---- TOP: DCS_{t+1} . [W_c ; W_s] for the rows that were still active at t + 1
     zero_acc(accD);
     if (st.nn[0] > 0) {
-        if (!group_wait(ctr + L, a.ntiles * k, a.status, &g_flag)) return false;         // stack backward of step t + 1
+        if (!group_wait(ctr + L * CTR_STRIDE, a.ntiles * k, a.status, &g_flag)) return false;         // stack backward of step t + 1
         const float* s0 = a_src(a.DCS, st.nbase[0], st.nn[0], a.ldcs, i, lane);
         const float* s1 = a_src(a.DCS, st.nbase[1], NA == 2 ? st.nn[1] : 0, a.ldcs, i, lane);
         const float* sx = dma_src(a.wcs_t, ub, a.ldcs, i, lane);
@@ -603,11 +603,11 @@ __device__ __forceinline__ bool step_bwd(const BwdArgs& a, float* lds, const int
         }
         TSTAMP(1);
         if (l == 0) break;
-        group_signal(ctr + l);
+        group_signal(ctr + l * CTR_STRIDE);
         // ---- P_l: accD = dgi_l . W_ih[l] (-> dh_{l-1}), accC = dgh_l . W_hh[l] (-> carry_l)
         zero_acc(accD);
         zero_acc(accC);
-        if (!group_wait(ctr + l, a.ntiles * (k + 1), a.status, &g_flag)) return false;
+        if (!group_wait(ctr + l * CTR_STRIDE, a.ntiles * (k + 1), a.status, &g_flag)) return false;
         TSTAMP(2);
         {
             const float* gi = a.DGI + (long long)l * a.NT * H3;
@@ -645,7 +645,7 @@ __device__ __forceinline__ bool step_bwd(const BwdArgs& a, float* lds, const int
     TSTAMP(5);
     if (!stack_bwd(stack_ctx(a, r0, off, t, g, j), ctr + 0, a.ntiles * (k + 1), a.status)) return false;     // waits for E_0 inside
     TSTAMP(6);
-    group_signal(ctr + L);
+    group_signal(ctr + L * CTR_STRIDE);
     // ---- carry_0 += dgh_0 . W_hh[0]: only this workgroup's next step needs it — it fills the hand-off latency
     {
         zero_acc(accC);
@@ -727,8 +727,8 @@ __global__ __launch_bounds__(256, 2) void k_seq_bwd(const BwdArgs a)
     }
     // the stack of step 0 read the INITIAL hidden state of the top layer: dh0[L-1] += DCS_0 . [W_c ; W_s]
     if (Tg > 0) {
-        int* ctr = a.ctr + (long long)g * (a.L + 1);
-        if (!group_wait(ctr + a.L, a.ntiles * Tg, a.status, &g_flag)) return;      // a hand-off never arrived (status word set; k_seq_poison makes it visible in every output)
+        int* ctr = a.ctr + (long long)g * (a.L + 1) * CTR_STRIDE;
+        if (!group_wait(ctr + a.L * CTR_STRIDE, a.ntiles * Tg, a.status, &g_flag)) return;      // a hand-off never arrived (status word set; k_seq_poison makes it visible in every output)
         const int i = 8 * wave + (lane >> 3), li = lane & 31, hh = lane >> 5, er = tid >> 3, c4 = (tid & 7) * 4, u = 32 * j + c4;
         f32x16 accD[2];
         zero_acc(accD);
@@ -793,7 +793,7 @@ size_t seq_bwd_persist_ws_bytes(int64_t B, int64_t H, int64_t L, int64_t W, int6
 {
     const int64_t ks = (W + 31) / 32 * 32;
     const int64_t G = ((B + 31) / 32 + 1) / 2;
-    return ppk_align_up(sizeof(float) * (size_t)3 * H * ks, 256) + ppk_align_up(sizeof(int) * (size_t)(G * (L + 1) + 64), 256)
+    return ppk_align_up(sizeof(float) * (size_t)3 * H * ks, 256) + ppk_align_up(sizeof(int) * (size_t)(G * (L + 1) * CTR_STRIDE + 64), 256)
            + ppk_align_up(sizeof(float) * (size_t)G * (size_t)(H / 32) * 64 * (size_t)ks, 256)
            + ppk_align_up(sizeof(float) * (size_t)B * (size_t)D * (size_t)W, 256);
 }
@@ -823,9 +823,9 @@ int seq_bwd_persist(int64_t T, const int64_t* bs, int64_t B, int64_t NT, int64_t
     for (int t = 0; t < (int)T; ++t) a.bs[t] = (int)bs[t];
     char* cur = (char*)ws;
     float* wx = (float*)ppk_carve(cur, sizeof(float) * (size_t)3 * H * ks);
-    const size_t nctr = (size_t)a.G * (size_t)(L + 1) + 64;
+    const size_t nctr = (size_t)a.G * (size_t)(L + 1) * CTR_STRIDE + 64;
     int* ctr = (int*)ppk_carve(cur, sizeof(int) * nctr);
-    a.wx = wx; a.ctr = ctr; a.status = ctr + (size_t)a.G * (size_t)(L + 1);
+    a.wx = wx; a.ctr = ctr; a.status = ctr + (size_t)a.G * (size_t)(L + 1) * CTR_STRIDE;
     a.xpart = (float*)ppk_carve(cur, sizeof(float) * (size_t)a.G * (size_t)a.ntiles * 64 * (size_t)ks);
     const size_t sbytes = sizeof(float) * (size_t)B * (size_t)D * (size_t)W;
     a.dS = (float*)ppk_carve(cur, sbytes);

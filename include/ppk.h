@@ -305,6 +305,22 @@ int ppk_hop_distances(const int64_t* esrc, const int64_t* edst, const int64_t* e
                       const int64_t* mat_ptr, int64_t n_seg, int64_t max_n, int networkx_order,
                       double* G, int64_t* order_out, int* status, ppk_stream_t stream);
 
+/* ---- device-side bundle sampler ---------------------------
+ * Replaces, for R root nodes at once, experiments/chem_reactions/utils.py:155-196 (the 2-hop bundle of load_data):
+ * max_close_neighbors distinct neighbours of the root (the head of a uniform permutation of its neighbour list), then
+ * uniformly chosen neighbours of those, round-robin, until max_total_bundle [root-or-close, neighbour] pairs or
+ * total_far draws; then the relabelling of nx.from_edgelist -> convert_node_labels_to_integers -> to_pandas_edgelist
+ * (nodes by first appearance, every undirected edge once, by node then adjacency insertion order).
+ * (rowptr, col): adjacency lists of the relation graph in networkx insertion order, N nodes.  roots [R] or NULL (= 0..R-1).
+ * The reference's single numpy Mersenne-Twister stream through all roots is replaced by one Philox4x32-10 stream per root
+ * (key = seed, counter = (draw index, 0, root)): same distribution, other numbers; oracle/bundle_sampler_ref.py replays the
+ * draws through the host restatement.  Outputs, per root r: shortlist [R, max_total, 2] original labels + n_short [R];
+ * labels [R, max_total + 1] original label of local node p + n_nodes [R]; edges [R, max_total, 2] local labels + n_edges [R].
+ * status [1] device int: non-zero when a root was outside [0, N).  max_total <= 32. */
+int ppk_sample_bundles(const int64_t* rowptr, const int64_t* col, int64_t N, const int64_t* roots, int64_t R,
+                       int max_close, int max_total, uint64_t seed, int64_t* shortlist, int* n_short,
+                       int64_t* labels, int* n_nodes, int64_t* edges, int* n_edges, int* status, ppk_stream_t stream);
+
 /* ---- K6: CSR build (stable sort of edge_index by target) --------------------
  * gcn_norm + the grouping that torch_scatter.scatter_add performs implicitly inside
  * torch_geometric GCNConv (reference reactions_infomax.py:60,66).

@@ -46,6 +46,7 @@ SIGNATURES = {
     'ppk_nt_small_grid_limit': (c_i64, [c_i64]),
     'ppk_mfma_mode': (c_int, [c_int]),
     'ppk_seq_persist_mode': (c_int, [c_int]),
+    'ppk_sample_bundles': (c_int, [ptr, ptr, c_i64, ptr, c_i64, c_int, c_int, ctypes.c_uint64, ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr]),
     'ppk_hop_distances': (c_int, [ptr, ptr, ptr, ptr, ptr, c_i64, c_i64, c_int, ptr, ptr, ptr, ptr]),
     'ppk_stackgru_seq_fwd_workspace_bytes': (c_sz, [c_i64, c_i64, c_i64, c_i64]),
     'ppk_stackgru_seq_fwd': (c_int, [c_i64, ptr, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64,

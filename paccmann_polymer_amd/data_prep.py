@@ -349,23 +349,84 @@ class Data:
             setattr(self, k, v)
 
 
-def load_data(filename, smiles_language, max_close_neighbors: int = 5, max_total_bundle: int = 20) -> List[Data]:
-    """Reference utils.py:101-198: one 2-hop bundle per node of the relation graph in
-    the JSON file (`smiles2nodes`, `edgelist`), sampled with the global numpy RNG.
-    `smiles_language` needs `smiles_to_token_indexes(str) -> list[int]`."""
-    import json
-    with open(filename, 'r') as f:
-        raw = json.load(f)
-    nodes2smiles = {v: k for k, v in raw['smiles2nodes'].items()}
+def adjacency_lists(edgelist):
+    """nx.from_edgelist(edgelist): adjacency lists in insertion order, duplicates merged (utils.py:112)."""
     adj = {}
-    for u, v in raw['edgelist']:            # nx.from_edgelist: adjacency in insertion order, duplicates merged
+    for u, v in edgelist:
         adj.setdefault(u, [])
         adj.setdefault(v, [])
         if v not in adj[u]:
             adj[u].append(v)
             if u != v:
                 adj[v].append(u)
+    return adj
+
+
+def adjacency_csr(adj):
+    """(rowptr, col) int64 numpy arrays of the adjacency lists of nodes 0 .. len(adj) - 1, insertion order kept."""
+    n = len(adj)
+    rowptr = np.zeros(n + 1, dtype=np.int64)
+    rowptr[1:] = np.cumsum([len(adj[x]) for x in range(n)])
+    col = np.fromiter((y for x in range(n) for y in adj[x]), dtype=np.int64, count=int(rowptr[-1]))
+    return rowptr, col
+
+
+def sample_bundles_device(rowptr, col, roots=None, max_close_neighbors: int = 5, max_total_bundle: int = 20, seed: int = 0,
+                          device=None):
+    """The bundles of `roots` (default: every node) sampled by ONE launch of `ppk_sample_bundles` (utils.py:155-196
+    with one Philox stream per root in place of numpy's global stream).  `rowptr`, `col`: adjacency lists in insertion
+    order (adjacency_csr).  Returns a dict of device tensors: shortlist [R, T, 2] / n_short [R] (original labels),
+    labels [R, T + 1] / n_nodes [R], edges [R, T, 2] / n_edges [R] (local labels, the order of
+    to_pandas_edgelist(convert_node_labels_to_integers(from_edgelist(shortlist))))."""
+    from . import _C
+    if device is None:
+        device = torch.device('cuda')
+    rp = torch.as_tensor(rowptr, dtype=torch.int64).to(device).contiguous()
+    cl = torch.as_tensor(col, dtype=torch.int64).to(device).contiguous()
+    N = rp.numel() - 1
+    if roots is not None:
+        roots = torch.as_tensor(roots, dtype=torch.int64)
+        if roots.numel() and (int(roots.min()) < 0 or int(roots.max()) >= N):
+            raise IndexError('root outside [0, num_nodes)')
+        roots = roots.to(device).contiguous()
+    R = N if roots is None else roots.numel()
+    T = int(max_total_bundle)
+    i64 = dict(dtype=torch.int64, device=device)
+    i32 = dict(dtype=torch.int32, device=device)
+    out = dict(shortlist=torch.zeros(R, T, 2, **i64), n_short=torch.zeros(R, **i32), labels=torch.zeros(R, T + 1, **i64),
+               n_nodes=torch.zeros(R, **i32), edges=torch.zeros(R, T, 2, **i64), n_edges=torch.zeros(R, **i32))
+    status = torch.zeros(1, **i32)
+    _C.check(_C.lib.ppk_sample_bundles(_C.p(rp), _C.p(cl), N, _C.p(roots), R, int(max_close_neighbors), T, int(seed) & (2 ** 64 - 1),
+                                       _C.p(out['shortlist']), _C.p(out['n_short']), _C.p(out['labels']), _C.p(out['n_nodes']),
+                                       _C.p(out['edges']), _C.p(out['n_edges']), _C.p(status), _C.stream()))
+    return out
+
+
+def load_data(filename, smiles_language, max_close_neighbors: int = 5, max_total_bundle: int = 20, sampler: str = 'host',
+              seed: int = 0) -> List[Data]:
+    """Reference utils.py:101-198: one 2-hop bundle per node of the relation graph in
+    the JSON file (`smiles2nodes`, `edgelist`).  sampler='host': sampled with the global numpy RNG, statement for
+    statement like the reference; sampler='device': all bundles in one kernel launch (`sample_bundles_device`, one Philox
+    stream per root keyed by `seed`: same distribution, other numbers than numpy's).
+    `smiles_language` needs `smiles_to_token_indexes(str) -> list[int]`."""
+    import json
+    with open(filename, 'r') as f:
+        raw = json.load(f)
+    nodes2smiles = {v: k for k, v in raw['smiles2nodes'].items()}
+    adj = adjacency_lists(raw['edgelist'])            # nx.from_edgelist: adjacency in insertion order, duplicates merged
     data = []
+    if sampler == 'device':
+        rowptr, col = adjacency_csr(adj)
+        out = {k: v.cpu().numpy() for k, v in sample_bundles_device(rowptr, col, None, max_close_neighbors, max_total_bundle, seed).items()}
+        for root in range(len(adj)):
+            nn, ne = int(out['n_nodes'][root]), int(out['n_edges'][root])
+            labels = out['labels'][root, :nn].tolist()
+            x = [torch.tensor(smiles_language.smiles_to_token_indexes(nodes2smiles[l])) for l in labels]
+            edge_index = np.ascontiguousarray(out['edges'][root, :ne].T)
+            data.append(Data(x=x, edge_index=torch.tensor(edge_index), num_nodes=len(x)))
+        return data
+    if sampler != 'host':
+        raise ValueError(sampler)
     for root in range(len(adj)):
         shortlist = sample_bundle(lambda x: adj[x], root, max_close_neighbors, max_total_bundle)
         labels, edge_index = relabel_bundle(shortlist)

@@ -32,7 +32,7 @@
 // agent-scope counter add; consumer = ONE lane polls (relaxed, agent), agent acquire (buffer_inv sc1),
 // vmcnt(0), workgroup barrier, then plain loads / LDS-DMA.  Every hand-off line is written once
 // before any reader touches it and by exactly one workgroup (128-byte row segments).  Polls are
-// 127 x 64 cycles apart (ppk_seq_common.h) and bounded: on a timeout (~3 s) the kernel raises a status
+// 32 x 64 cycles apart on counters that sit 4 KB apart (ppk_seq_common.h) and bounded: on a timeout (~3 s) the kernel raises a status
 // word, every workgroup leaves at its next wait and a NaN is written into the result.
 #include "ppk_common.h"
 #include "ppk_kernels.h"

@@ -14,6 +14,48 @@ template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_wai
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 // the K loop of the sequence kernels in miniature: block 0 of a stage optionally comes from a cold buffer (the activation
 // rows: first touch, beyond L2), NM MFMAs (32x32x2 fp32) per wave and stage on the fragments read from LDS
+// k_loop with the stage's four loads issued BETWEEN its MFMAs (one after every NM / 4) instead of in a burst behind the barrier
+template <int DEPTH, int NM>
+__global__ __launch_bounds__(256, 2) void k_loop_spread(const float* src, const float* cold, int pitch_f, int ktiles, int stages, float* out)
+{
+    __shared__ __align__(1024) float lds[DEPTH + 1][4096];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i = 8 * wave + (lane >> 3);
+    const float* base = src + (size_t)(blockIdx.x % 16) * 160 * pitch_f + (size_t)i * pitch_f + 4 * ((lane & 7) ^ ((i >> 1) & 7));
+    f32x16 acc[3];
+    for (int q = 0; q < 3; ++q) for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
+    int kt = 0;
+    const int xo = (lane & 31) * 32 + 4 * ((2 * wave + (lane >> 5)) ^ (((lane & 31) >> 1) & 7));
+    for (int p = 0; p < DEPTH; ++p) {
+        const float* q = base + (size_t)(kt++ % ktiles) * 32;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) __builtin_amdgcn_global_load_lds(q + (size_t)b * 32 * pitch_f, LDSP(&lds[p][b * 1024 + wave * 256]), 16, 0, 0);
+    }
+    int cur = 0, nxt = DEPTH;
+    for (int it = 0; it < stages; ++it) {
+        wait_vm<4 * (DEPTH - 1)>();
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        f32x4 f[4];
+#pragma unroll
+        for (int b = 0; b < 4; ++b) f[b] = *(const f32x4*)&lds[cur][b * 1024 + xo];
+        const float* q = base + (size_t)(kt++ % ktiles) * 32;
+#pragma unroll
+        for (int m = 0; m < NM; ++m) {
+            acc[m % 3] = __builtin_amdgcn_mfma_f32_32x32x2f32(f[0][m & 3], f[1 + m % 3][m & 3], acc[m % 3], 0, 0, 0);
+            if (m % (NM / 4) == NM / 4 - 1) {
+                const int b = m / (NM / 4);
+                __builtin_amdgcn_global_load_lds(q + (size_t)b * 32 * pitch_f, LDSP(&lds[nxt][b * 1024 + wave * 256]), 16, 0, 0);
+            }
+        }
+        nxt = nxt == DEPTH ? 0 : nxt + 1;
+        cur = cur == DEPTH ? 0 : cur + 1;
+    }
+    wait_vm<0>();
+    float t = 0.f;
+    for (int q = 0; q < 3; ++q) for (int r = 0; r < 16; ++r) t += acc[q][r];
+    if (t == 12345.678f) out[tid] = t;
+}
+
 // k_loop with the fragments of stage it + 1 read from LDS BEFORE the MFMAs of stage it are issued (register double buffer):
 // the barrier -> fragment read -> first MFMA chain leaves the critical path
 template <int DEPTH, int NM>
@@ -266,6 +308,9 @@ int main()
         for (int grid : {256, 512}) {
             run2("K loop, L2-resident, 12 MFMA, depth 3", k_loop<3, false, 12>, grid);
             run2("K loop, L2-resident, 24 MFMA, depth 2", k_loop<2, false, 24>, grid);
+            run2("K loop SPREAD loads, 12 MFMA, depth 3", k_loop_spread<3, 12>, grid);
+            run2("K loop SPREAD loads, 24 MFMA, depth 3", k_loop_spread<3, 24>, grid);
+            run2("K loop SPREAD loads, 12 MFMA, depth 2", k_loop_spread<2, 12>, grid);
             run2("K loop PIPELINED frags, 12 MFMA, depth 3", k_loop_pipe<3, 12>, grid);
             run2("K loop PIPELINED frags, 24 MFMA, depth 3", k_loop_pipe<3, 24>, grid);
             run2("K loop, L2-resident, 0 MFMA, depth 3", k_loop<3, false, 0>, grid);

@@ -159,8 +159,10 @@ int64_t ppk_nt_small_grid_limit(int64_t limit);
 /* Launch schedule of K1 (ppk_stackgru_seq_fwd / _bwd).  Two schedules compute the same step: the whole time loop as ONE
  * persistent launch per pass (row-block groups synchronised among their own workgroups only), or one launch per
  * layer-step.  mode:
- *   -1  auto (default; PPK_SEQ_PERSIST in the environment): persistent from batch 1024 up (where it is faster on
- *       MI355X, tools/persist_threshold.py), per-step launches below;
+ *   -1  auto (default; PPK_SEQ_PERSIST in the environment): persistent where it is faster on MI355X — when the batch's
+ *       row-block groups (64 rows x H / 32 workgroups each) make one machine-full that is at least 3/8 full at H >= 384
+ *       (9/10 at H >= 256) or two that are at least 9/10 full at H >= 512: e.g. H 512 from batch 1024 to 4096, H 256 at batch
+ *       4096, never at H 128 (tools/persist_threshold_shapes.py, profiles/r03_persist_shapes.txt) —, per-step launches elsewhere;
  *    0  never persistent;
  *    1  persistent at ANY batch, wherever the shape is supported (H % 32 == 0, ks / ldcs at their minimal paddings
  *       roundup32(W) / roundup32(3 + W), one group's workgroups resident together on the current device); an
@@ -180,8 +182,9 @@ int ppk_seq_persist_mode(int mode);
  *      oracle on the full model at BASELINE configs[0] size (tests/test_gpu_bf16.py::test_bf16_step_vs_fp64_oracle_configs0):
  *      losses 1e-2 relative, latents 2e-2, every gradient tensor within 1e-1 of its largest entry, cosine >= 0.99
  *      (measured: losses 1e-4, worst gradient 3e-2).
- * In K1 it takes effect only where the persistent kernels run: in auto mode (ppk_seq_persist_mode -1) that is from
- * batch 1024 up — below it mode 1 changes nothing in K1 unless ppk_seq_persist_mode(1) forces the persistent launch.  Any other
+ * In K1 it takes effect only where the persistent kernels run: in auto mode (ppk_seq_persist_mode -1) that is where the
+ * rule above picks them (H 512: from batch 1024 up) — elsewhere mode 1 changes nothing in K1 unless ppk_seq_persist_mode(1)
+ * forces the persistent launch.  Any other
  * value only queries.  Process-global.  Returns the value in force. */
 int ppk_mfma_mode(int mode);
 

@@ -43,10 +43,16 @@ int gemm_ntF(const NtProblem* ps, int count, hipStream_t stream);    // 128 x (3
 
 // ---- persistent StackGRU sequence kernels (ppk_seq_persist.hip): the whole time loop in one launch,
 //      row-block groups synchronised only among their own workgroups ----
-// auto mode (ppk_seq_persist_mode(-1)): the persistent launch is taken from this batch size up.  Measured on MI355X
-// (tools/persist_threshold.py, H 512, L 2, len 20..100; training step, per-step launches vs persistent, ms):
-// B 16: 16.0 / 21.6, 64: 17.2 / 29.9, 256: 19.7 / 28.7, 512: 28.4 / 30.3, 1024: 35.4 / 33.8, 2048: 53.3 / 47.2
-constexpr int SEQP_AUTO_MIN_B = 1024;
+// auto mode (ppk_seq_persist_mode(-1)): which schedule runs a batch of B rows at hidden size H.  A group (64 rows) is
+// H / 32 workgroups and a launch carries at most one machine-full of whole groups; the persistent launch pays its
+// per-timestep hand-off chain once per machine-full, the per-step launches pay per tile.  Measured on MI355X over
+// H 128 .. 1024, L 1 .. 3, B 512 .. 4096 (tools/persist_threshold_shapes.py, profiles/r03_persist_shapes.txt; training
+// step, persistent / per-step): the persistent launch wins (0.84 .. 0.99) with ONE machine-full that is at least 3/8 full
+// at H >= 384 (or at least 9/10 full at H >= 256), and with two machine-fulls that are at least 9/10 full at H >= 512; it loses
+// (1.01 .. 2.0) at H = 128, with a half-empty second machine-full, and from three machine-fulls up.
+// H 512, L 2 (tools/persist_threshold.py; per-step / persistent, ms): B 16: 16.0 / 21.6, 64: 17.2 / 29.5, 256: 19.9 / 27.8,
+// 512: 27.3 / 29.3, 1024: 35.4 / 33.0, 2048: 52.9 / 45.5
+bool seq_auto_persistent(int64_t B, int64_t H, int groups_per_launch, int capacity);
 constexpr int SEQP_MAXT = 512, SEQP_MAXL = 8;
 int mfma_mode(int mode = -1);        // 0 fp32 operands (default), 1 bf16 operands; other values only query
 int seq_persist_mode(int mode);      // -1 auto (default), 0 never, 1 whenever supported; other values only query

@@ -689,6 +689,17 @@ int seq_capacity(const void* kernel, int slot)
     return cache[dev][slot] < 0 ? 0 : cache[dev][slot];
 }
 
+// auto mode: persistent or per-step launches (ppk_kernels.h has the measurements behind the rule)
+bool seq_auto_persistent(int64_t B, int64_t H, int groups_per_launch, int capacity)
+{
+    const int64_t ntiles = H / 32, G = ((B + 31) / 32 + 1) / 2, W = G * ntiles;
+    if (groups_per_launch < 1 || capacity < 1) return false;
+    const int64_t fulls = (G + groups_per_launch - 1) / groups_per_launch;
+    if (fulls == 1) return (ntiles >= 12 && 8 * W >= 3 * (int64_t)capacity) || (ntiles >= 8 && 10 * W >= 9 * (int64_t)capacity);
+    if (fulls == 2) return ntiles >= 16 && 10 * W >= 18 * (int64_t)capacity;
+    return false;
+}
+
 // groups per launch for `capacity` resident workgroups under the XCD placement (xt, tpx); 0 = a group does not fit
 int seq_groups_per_launch(int capacity, int ntiles, int xt, int tpx)
 {
@@ -728,7 +739,6 @@ double seq_row_share(const int* bs, int T, int G, int MT, int pair, int g0, int 
 bool seq_fwd_persist_ok(int64_t T, int64_t B, int64_t NT, int64_t H, int64_t L, int64_t W, int64_t D, int64_t ks, int64_t ldcs)
 {
     if (force_mode() == 0) return false;
-    if (force_mode() == -1 && B < ppk::SEQP_AUTO_MIN_B) return false;       // auto: below this the per-layer-step launches are faster (tools/persist_threshold.py)
     if (T < 1 || T > MAXT || L < 1 || L > MAXL || H % 32 || H > 2048 || ks % 32 || ks > 512 || NT >= (1LL << 31) || B > (1 << 24)) return false;
     // the workspace (seq_fwd_persist_ws_bytes) is sized for the minimal paddings: a caller with wider ones takes the per-step path
     if (ldcs != (3 + W + 31) / 32 * 32 || ks != (W + 31) / 32 * 32) return false;
@@ -739,7 +749,9 @@ bool seq_fwd_persist_ok(int64_t T, int64_t B, int64_t NT, int64_t H, int64_t L, 
     int xt, tpx;
     seq_placement((int)(H / 32), xt, tpx);
     const int cap = ppk::mfma_mode() == 1 ? seq_capacity((const void*)k_seq_fwd<true>, 1) : seq_capacity((const void*)k_seq_fwd<false>, 0);
-    if (seq_groups_per_launch(cap, (int)(H / 32), xt, tpx) < 1) return false;
+    const int gpl = seq_groups_per_launch(cap, (int)(H / 32), xt, tpx);
+    if (gpl < 1) return false;
+    if (force_mode() == -1 && !seq_auto_persistent(B, H, gpl, cap)) return false;      // auto: the per-layer-step launches are faster here
     return true;
 }
 

@@ -774,7 +774,6 @@ namespace ppk {
 bool seq_bwd_persist_ok(int64_t T, int64_t B, int64_t NT, int64_t H, int64_t L, int64_t W, int64_t D, int64_t ks, int64_t ldcs)
 {
     if (seq_persist_mode(-2) == 0) return false;
-    if (seq_persist_mode(-2) == -1 && B < ppk::SEQP_AUTO_MIN_B) return false;
     if (T < 1 || T > MAXT || L < 1 || L > MAXL || H % 32 || H > 2048 || ks % 32 || ks > 64 || NT >= (1LL << 31) || B > (1 << 24)) return false;
     // the workspace (seq_bwd_persist_ws_bytes) is sized for the minimal paddings: a caller with wider ones takes the per-step path
     if (ldcs != (3 + W + 31) / 32 * 32 || ks != (W + 31) / 32 * 32 || ldcs > 512) return false;
@@ -785,7 +784,9 @@ bool seq_bwd_persist_ok(int64_t T, int64_t B, int64_t NT, int64_t H, int64_t L, 
     int xt, tpx;
     seq_placement((int)(H / 32), xt, tpx);
     const int cap = ppk::mfma_mode() == 1 ? seq_capacity((const void*)k_seq_bwd<true>, 3) : seq_capacity((const void*)k_seq_bwd<false>, 2);
-    if (seq_groups_per_launch(cap, (int)(H / 32), xt, tpx) < 1) return false;      // a group does not fit this device: per-step path
+    const int gpl = seq_groups_per_launch(cap, (int)(H / 32), xt, tpx);
+    if (gpl < 1) return false;                                                      // a group does not fit this device: per-step path
+    if (seq_persist_mode(-2) == -1 && !seq_auto_persistent(B, H, gpl, cap)) return false;
     return true;
 }
 

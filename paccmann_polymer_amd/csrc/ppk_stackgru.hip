@@ -18,10 +18,11 @@
 //   XS    [NT, ks]    stack top fed to layer 0 (ks = W rounded up to 32, zero padded)
 // Two launch schedules behind the same entry points (ppk_seq_persist_mode):
 //  * persistent (ppk_seq_persist.hip / ppk_seq_persist_bwd.hip): the whole time loop in ONE launch per pass,
-//    row-block groups synchronised among their own workgroups only — taken from batch 1024 up in auto mode;
+//    row-block groups synchronised among their own workgroups only — taken in auto mode where the groups fill the
+//    machine (H 512: from batch 1024 up; ppk::seq_auto_persistent);
 //  * per-step launches (this file): the gate contractions as fp32-MFMA GEMMs (ppk_gemm_nt.hip) with the GRU gate
-//    math fused into their epilogues, 2 + L launches per timestep — faster below batch 1024, where a group's 16
-//    workgroups cannot fill the machine ("Small batches").
+//    math fused into their epilogues, 2 + L launches per timestep — faster where the groups' workgroups
+//    cannot fill the machine or need three or more machine-fulls ("Small batches").
 // Per step (forward):   stack update -> {cell 0 (K = ks, + table[token]) ; W_hh[L-1] h of the previous step}
 // -> for l >= 1 {cell l ; W_hh[l-1] h for the NEXT step} -> stack heads for the next step.
 // The embedding half of the layer-0 input product is hoisted out of the time loop:
@@ -406,8 +407,9 @@ int ppk_stackgru_seq_bwd(int64_t T, const int64_t* batch_sizes_host, int64_t B, 
     return ppk::gemm_nt64(&p, 1, stream);
 }
 
-// Launch schedule of the sequence entry points: -1 = auto (default: the persistent kernels from batch
-// ppk::SEQP_AUTO_MIN_B = 1024 up, where they are faster; the per-step launches below), 0 = never persistent,
+// Launch schedule of the sequence entry points: -1 = auto (default: the persistent kernels where they are faster —
+// ppk::seq_auto_persistent: one or two well-filled machine-fulls of workgroups, e.g. H 512 from batch 1024 up —,
+// the per-step launches elsewhere), 0 = never persistent,
 // 1 = persistent whenever the shape is supported, at any batch; any other value only queries.  Returns the value in force.
 int ppk_seq_persist_mode(int mode) { return ppk::seq_persist_mode(mode); }
 int ppk_mfma_mode(int mode) { return ppk::mfma_mode(mode); }

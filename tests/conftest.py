@@ -22,7 +22,7 @@ def golden_dir():
 @pytest.fixture(params=['per_step_launches', 'persistent_launch'])
 def seq_schedule(request):
     """Runs a test under both launch schedules of the K1 sequence entry points (ppk_seq_persist_mode 0 / 1): auto
-    mode picks the persistent launch only from batch 1024 up, so the parity cases (small batches) would otherwise
+    mode picks the persistent launch only where the batch fills the machine (H 512: from batch 1024 up), so the parity cases (small batches) would otherwise
     never reach it.  Mode 1 falls back to the per-step launches where a shape is unsupported."""
     from paccmann_polymer_amd import _C
     mode = 0 if request.param == 'per_step_launches' else 1

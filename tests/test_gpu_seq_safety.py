@@ -121,3 +121,40 @@ def test_wider_paddings_than_the_workspace_query_take_the_per_step_path():
     assert float((S_a - S_b).abs().max()) <= 2e-5
     assert float((CS_a[:, :3 + W] - CS_b[:, :3 + W]).abs().max()) <= 2e-5
     assert float((XS_a[:, :W] - XS_b[:, :W]).abs().max()) <= 2e-5
+
+
+def _seq_kernels_launched(H, B, T=6):
+    """Which sequence-kernel families one encoder forward + backward launches in AUTO mode (profiling table of the library)."""
+    from torch.nn.utils.rnn import pack_sequence
+    from paccmann_polymer_amd import _C
+    from paccmann_polymer_amd import stack_gru_vae as M
+    lib = _C.lib
+    params = dict(vocab_size=32, embedding_size=32, rnn_cell_size=H, n_layers=2, stack_width=10, stack_depth=8,
+                  latent_dim=16, dropout=0.0, padding_index=0, batch_size=1, batch_mode='packed')
+    torch.manual_seed(0)
+    enc_net = M.StackGRUEncoder(params).cuda()
+    rng = np.random.default_rng(B + H)
+    seqs = [torch.tensor(np.concatenate([[2], rng.integers(4, 32, size=int(rng.integers(2, T))), [3]])) for _ in range(B)]
+    enc = pack_sequence(seqs, enforce_sorted=False)
+    assert lib.ppk_seq_persist_mode(-1) == -1
+    lib.ppk_prof_enable(1)
+    mu, lv = enc_net.encoder_train_step(enc)
+    (mu.sum() + lv.sum()).backward()
+    torch.cuda.synchronize()
+    lib.ppk_prof_enable(0)
+    nk = lib.ppk_prof_kind_count()
+    ms, work, launches = (ctypes.c_double * nk)(), (ctypes.c_double * nk)(), (ctypes.c_int64 * nk)()
+    lib.ppk_prof_collect(ms, work, launches)
+    return {lib.ppk_prof_kind_name(k).decode() for k in range(nk) if launches[k]}
+
+
+@pytest.mark.parametrize('H,B,persistent', [
+    (512, 1024, True), (512, 2048, True), (512, 512, False), (128, 2048, False), (256, 2048, False), (256, 4096, True),
+    (384, 1024, True), (768, 512, True), (768, 2048, False), (1024, 512, True),
+])
+def test_auto_mode_picks_the_measured_faster_schedule(H, B, persistent):
+    """ppk_seq_persist_mode(-1): the rule of seq_auto_persistent over batch AND hidden size (a group is H / 32 workgroups;
+    profiles/r03_persist_shapes.txt has the timings of both schedules at these shapes)."""
+    kinds = _seq_kernels_launched(H, B)
+    assert ('k_seq_fwd' in kinds) == persistent, (H, B, sorted(kinds))
+    assert ('k_seq_bwd' in kinds) == persistent, (H, B, sorted(kinds))

@@ -310,7 +310,11 @@ def main():
                     step_breakdown_ms={d['kernel']: round(d['ms'], 3) for d in kinds})
 
     if args.bundles == 128 and args.bundle_nodes == 16:
-        roofline.update(pmc_traffic(top['kernel']))
+        if args.dtype == 'f32':
+            roofline.update(pmc_traffic(top['kernel']))
+        else:
+            roofline['traffic_note'] = 'the committed PMC passes were taken in fp32 mode: no traffic figure for the bf16-operand variant'
+
 
     out = dict(metric='training samples/sec (whole node)', value=round(B * world / (dt / args.steps), 1),
                unit='samples/s', n_gpus=world, steps=args.steps, warmup=args.warmup,

@@ -322,7 +322,8 @@ int ppk_hop_distances(const int64_t* esrc, const int64_t* edst, const int64_t* e
  * (key = seed, counter = (draw index, 0, root)): same distribution, other numbers; oracle/bundle_sampler_ref.py replays the
  * draws through the host restatement.  Outputs, per root r: shortlist [R, max_total, 2] original labels + n_short [R];
  * labels [R, max_total + 1] original label of local node p + n_nodes [R]; edges [R, max_total, 2] local labels + n_edges [R].
- * status [1] device int: non-zero when a root was outside [0, N).  max_total <= 32. */
+ * status [1] device int: bit 0 when a root was outside [0, N), bit 1 when a neighbour id of a root was (those roots get empty
+ * bundles; nothing is read through a bad id).  max_total <= 32. */
 int ppk_sample_bundles(const int64_t* rowptr, const int64_t* col, int64_t N, const int64_t* roots, int64_t R,
                        int max_close, int max_total, uint64_t seed, int64_t* shortlist, int* n_short,
                        int64_t* labels, int* n_nodes, int64_t* edges, int* n_edges, int* status, ppk_stream_t stream);

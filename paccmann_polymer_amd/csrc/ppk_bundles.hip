@@ -70,6 +70,11 @@ __global__ __launch_bounds__(64) void k_sample_bundles(const int64_t* __restrict
         for (int m = i; m > at; --m) taken[m] = taken[m - 1];
         taken[at] = idx;
         close[i] = col[r0 + idx];
+        if (close[i] < 0 || close[i] >= N) {          // a column outside the graph: nothing is read through it
+            atomicOr(status, 2);
+            n_short[r] = 0; n_nodes[r] = 0; n_edges[r] = 0;
+            return;
+        }
         total_far += rowptr[close[i] + 1] - rowptr[close[i]];
         sl[2 * i] = root; sl[2 * i + 1] = close[i];
     }

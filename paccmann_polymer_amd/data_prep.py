@@ -399,6 +399,8 @@ def sample_bundles_device(rowptr, col, roots=None, max_close_neighbors: int = 5,
     _C.check(_C.lib.ppk_sample_bundles(_C.p(rp), _C.p(cl), N, _C.p(roots), R, int(max_close_neighbors), T, int(seed) & (2 ** 64 - 1),
                                        _C.p(out['shortlist']), _C.p(out['n_short']), _C.p(out['labels']), _C.p(out['n_nodes']),
                                        _C.p(out['edges']), _C.p(out['n_edges']), _C.p(status), _C.stream()))
+    if int(status.item()) != 0:                    # start-up path: one read-back is affordable
+        raise IndexError('adjacency lists hold a node id outside [0, num_nodes)')
     return out
 
 

@@ -111,6 +111,22 @@ class SparseRelationGraph:
         return self._anchor_starts[key]
 
 
+def _gloo(group):
+    return dist.get_backend(group) == 'gloo'
+
+
+def _all_reduce_inplace(t, op, group):
+    """all-reduce of a device tensor; under gloo (rehearsals / tests with several ranks sharing one GPU) through host
+    memory: gloo's collectives on device tensors of two processes that share a card have stalled, RCCL —
+    the production backend — never takes this branch."""
+    if t.is_cuda and _gloo(group):
+        h = t.cpu()
+        dist.all_reduce(h, op=op, group=group)
+        t.copy_(h)
+    else:
+        dist.all_reduce(t, op=op, group=group)
+
+
 class _SparseGraphLoss(torch.autograd.Function):
 
     @staticmethod
@@ -134,12 +150,12 @@ class _SparseGraphLoss(torch.autograd.Function):
         if group is not False:
             off = _lib.ppk_graphreg_sparse_max_ptr(_C.p(ws), N, E) - base
             m = ws[off:off + 4].view(torch.float32)
-            dist.all_reduce(m, op=dist.ReduceOp.MAX, group=group)
+            _all_reduce_inplace(m, dist.ReduceOp.MAX, group)
         _C.check(_lib.ppk_graphreg_sparse_terms(N, E, _C.p(graph.rowptr), _C.p(graph.col), a0, a1, _C.p(ws), wsb, st))
         if group is not False:
             off = _lib.ppk_graphreg_sparse_sum_ptr(_C.p(ws), N, E) - base
             s = ws[off:off + 16].view(torch.float64)          # [S, number of tied maximal edges]: both are sums over ranks
-            dist.all_reduce(s, op=dist.ReduceOp.SUM, group=group)
+            _all_reduce_inplace(s, dist.ReduceOp.SUM, group)
         loss = torch.empty(1, dtype=torch.float32, device=dev)
         _C.check(_lib.ppk_graphreg_sparse_finish(N, E, _C.p(loss), _C.p(ws), wsb, st))
         ctx.save_for_backward(z, ws)
@@ -171,8 +187,14 @@ class _AllGatherRows(torch.autograd.Function):
         mine = z_local.contiguous()
         if mine.shape[0] < cmax:
             mine = torch.cat([mine, mine.new_zeros(cmax - mine.shape[0], mine.shape[1])])
-        parts = [torch.empty_like(mine) for _ in counts]
-        dist.all_gather(parts, mine, group=group)
+        if mine.is_cuda and _gloo(group):          # through host memory (see _all_reduce_inplace)
+            mine_h = mine.cpu()
+            parts_h = [torch.empty_like(mine_h) for _ in counts]
+            dist.all_gather(parts_h, mine_h, group=group)
+            parts = [p.to(mine.device) for p in parts_h]
+        else:
+            parts = [torch.empty_like(mine) for _ in counts]
+            dist.all_gather(parts, mine, group=group)
         ctx.rank = rank
         return torch.cat([p[:c] for p, c in zip(parts, counts)], dim=0)
 
@@ -187,7 +209,7 @@ class _AllGatherRows(torch.autograd.Function):
             out = out[:ctx.counts[ctx.rank]]
         else:                                   # gloo (CPU-side tests) has no reduce_scatter
             full = dz_full.contiguous().clone()
-            dist.all_reduce(full, op=dist.ReduceOp.SUM, group=ctx.group)
+            _all_reduce_inplace(full, dist.ReduceOp.SUM, ctx.group)
             out = torch.split(full, ctx.counts, dim=0)[ctx.rank].contiguous()
         return out, None, None
 

@@ -133,3 +133,11 @@ def test_load_data_device_sampler(tmp_path):
         assert torch.equal(d.edge_index, torch.tensor(ei).reshape(2, -1))
         for xt, l in zip(d.x, labels):
             assert xt.tolist() == Lang().smiles_to_token_indexes(inv[l])
+
+
+def test_bad_neighbour_id_is_reported_not_dereferenced():
+    rowptr = np.array([0, 2, 3, 4], dtype=np.int64)
+    col = np.array([1, 7, 0, 0], dtype=np.int64)          # node 0 lists a neighbour 7 of a 3-node graph
+    with pytest.raises(IndexError):
+        for seed in range(8):                              # whichever draw picks it
+            data_prep.sample_bundles_device(rowptr, col, None, 5, 20, seed)

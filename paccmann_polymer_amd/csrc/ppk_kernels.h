@@ -55,7 +55,8 @@ int gemm_ntF(const NtProblem* ps, int count, hipStream_t stream);    // 128 x (3
 bool seq_auto_persistent(int64_t B, int64_t H, int groups_per_launch, int capacity);
 constexpr int SEQP_MAXT = 512, SEQP_MAXL = 8;
 int mfma_mode(int mode = -1);        // 0 fp32 operands (default), 1 bf16 operands; other values only query
-int seq_persist_mode(int mode);      // -1 auto (default), 0 never, 1 whenever supported; other values only query
+int seq_persist_mode(int mode);      // -1 auto (default), 0 never, 1 row-block persistent whenever supported, 2 = auto + the small-batch
+                                     // weights-stationary kernels whenever supported; other values only query
 bool seq_fwd_persist_ok(int64_t T, int64_t B, int64_t NT, int64_t H, int64_t L, int64_t W, int64_t D, int64_t ks, int64_t ldcs);
 size_t seq_fwd_persist_ws_bytes(int64_t B, int64_t H, int64_t L, int64_t W);
 int seq_fwd_persist(int64_t T, const int64_t* bs, int64_t B, int64_t NT, int64_t V, int64_t H, int64_t L, int64_t W, int64_t D,
@@ -64,6 +65,16 @@ int seq_fwd_persist(int64_t T, const int64_t* bs, int64_t B, int64_t NT, int64_t
                     const float* wcs, const float* bcs, const float* h0, const float* S0,
                     float* XS, float* Hs, float* HP, float* gates, float* S, float* CS, int64_t ldcs,
                     const float* drop, float* Hdrop, void* ws, size_t ws_bytes, hipStream_t stream);
+
+// ---- small-batch (<= 32 rows) weights-stationary forward (ppk_seq_ws.hip): H / 16 workgroups keep their gate rows of
+//      every matrix in registers for the whole launch; same arguments, outputs and workspace as seq_fwd_persist ----
+bool seq_fwd_ws_ok(int64_t T, int64_t B, int64_t NT, int64_t H, int64_t L, int64_t W, int64_t D, int64_t ks, int64_t ldcs);
+int seq_fwd_ws(int64_t T, const int64_t* bs, int64_t B, int64_t NT, int64_t V, int64_t H, int64_t L, int64_t W, int64_t D,
+               const int64_t* tokens, const float* table, const float* wx0s, int64_t ks,
+               const float* const* w_ih, const float* const* w_hh, const float* const* b_ih, const float* const* b_hh,
+               const float* wcs, const float* bcs, const float* h0, const float* S0,
+               float* XS, float* Hs, float* HP, float* gates, float* S, float* CS, int64_t ldcs,
+               const float* drop, float* Hdrop, void* ws, size_t ws_bytes, hipStream_t stream);
 
 // shared host helpers of the two persistent kernels (ppk_seq_persist.hip)
 int seq_poison(const int* status, float* const* ptrs, const long long* counts, int n, hipStream_t stream);

@@ -660,7 +660,7 @@ int mfma_mode(int mode)
 
 int seq_persist_mode(int mode)
 {
-    if (mode >= -1 && mode <= 1) g_force = mode;
+    if (mode >= -1 && mode <= 2) g_force = mode;
     return force_mode();
 }
 
@@ -751,7 +751,7 @@ bool seq_fwd_persist_ok(int64_t T, int64_t B, int64_t NT, int64_t H, int64_t L, 
     const int cap = ppk::mfma_mode() == 1 ? seq_capacity((const void*)k_seq_fwd<true>, 1) : seq_capacity((const void*)k_seq_fwd<false>, 0);
     const int gpl = seq_groups_per_launch(cap, (int)(H / 32), xt, tpx);
     if (gpl < 1) return false;
-    if (force_mode() == -1 && !seq_auto_persistent(B, H, gpl, cap)) return false;      // auto: the per-layer-step launches are faster here
+    if (force_mode() != 1 && !seq_auto_persistent(B, H, gpl, cap)) return false;      // auto (and mode 2 beyond the small-batch kernel's shapes): the per-layer-step launches are faster here
     return true;
 }
 

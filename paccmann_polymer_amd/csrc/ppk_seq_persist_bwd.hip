@@ -786,7 +786,7 @@ bool seq_bwd_persist_ok(int64_t T, int64_t B, int64_t NT, int64_t H, int64_t L, 
     const int cap = ppk::mfma_mode() == 1 ? seq_capacity((const void*)k_seq_bwd<true>, 3) : seq_capacity((const void*)k_seq_bwd<false>, 2);
     const int gpl = seq_groups_per_launch(cap, (int)(H / 32), xt, tpx);
     if (gpl < 1) return false;                                                      // a group does not fit this device: per-step path
-    if (seq_persist_mode(-2) == -1 && !seq_auto_persistent(B, H, gpl, cap)) return false;
+    if (seq_persist_mode(-2) != 1 && !seq_auto_persistent(B, H, gpl, cap)) return false;
     return true;
 }
 

@@ -1,0 +1,471 @@
+// K1 forward for SMALL batches (<= 32 sequences: the reference's own regime, one bundle of <= 21 SMILES per optimizer
+// step, experiments/chem_reactions/reactions_vae.py:52-59) as ONE persistent launch with the weights STATIONARY IN
+// REGISTERS (paccmann_chemistry StackGRU reached from paccmann_polymer/models/paccmann_encoder.py:166,168; semantics
+// SURVEY.md Appendix B).
+//
+// With <= 32 rows the per-step launches and the row-block persistent kernel (ppk_seq_persist.hip) both spend a timestep
+// streaming every weight (9.8 MB at H 512, L 2) past one or two 32-row tiles: ~35 us per timestep on 16 CUs.  Here the
+// hidden units are dealt 16 to a workgroup (H / 16 workgroups of 512 threads, one per CU) and a workgroup keeps ITS gate
+// rows of every matrix — r, z, n of its 16 units: 48 x (ks + (2L-1) H) floats = 307 KB at H 512, L 2 — in the VGPRs of its
+// eight waves for the whole launch (150 registers per lane), as A operands of v_mfma_f32_16x16x4_f32:
+//     D[unit][row] += W[unit][k] . x[row][k]       (M = 16 gate rows, N = 16 batch rows, K = 4)
+// The eight waves split K; a lane's B operands are 16 consecutive floats of one activation row, loaded straight from
+// global memory into registers (no LDS staging: the activations are 2 KB per row).  Only activations move: per timestep
+// a workgroup reads the rows' stack tops and hidden states (<= 32 x 4.4 KB) and writes its 16 units of them.
+// The eight K-chunk partial tiles are summed in wave order through LDS (fixed order: bitwise reproducible), the GRU
+// cell runs on the sums, and the stack heads are split over the workgroups as in ppk_seq_persist.hip (every workgroup
+// multiplies its 16 units with its slice of [W_c; W_s], the row's owner adds the partials in workgroup order).  The
+// owner of a row keeps that row's stack in LDS for the whole launch (global S is write-only here).
+//
+// Order inside a timestep (L >= 2):  W_hh0 h_0(t-1)  |wait heads| stack update of the owned rows |signal x|
+//   |wait x| W_ih0 x(t), cell 0 |signal h_0|  W_hh1 h_1(t-1)  |wait h_0| W_ih1 h_0(t), cell 1, heads partial |signal h_1, heads|
+// — the products that need nothing new sit in front of the waits.  Three hand-offs per timestep, the protocol of
+// ppk_seq_common.h (sc1 write-through stores, every wave drains, barrier, one agent-scope add; one lane polls, acquire,
+// barrier, sc1 loads to registers).
+#include "ppk_common.h"
+#include "ppk_kernels.h"
+#include "ppk_seq_common.h"
+#include <algorithm>
+
+namespace {
+
+using namespace ppk_seq;
+
+constexpr int MAXT = ppk::SEQP_MAXT;
+constexpr int NTH = 512;                       // 8 waves: two per SIMD, 256 registers each
+constexpr int WROWS = 32;                      // batch rows of a launch (two 16-row MFMA tiles)
+constexpr int STACK_FLOATS = 12288;            // LDS for the owned rows' stacks (two images per row)
+constexpr int WS_MAXL = 2;
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+struct WsArgs {
+    int T, B, W, D, V, ldcs, DW;
+    long long NT;
+    const int64_t* tokens;
+    const float* table; const float* wx0s;
+    const float* w_ih[WS_MAXL]; const float* w_hh[WS_MAXL]; const float* b_ih[WS_MAXL]; const float* b_hh[WS_MAXL];
+    const float* wcs_t; const float* bcs; const float* h0; const float* S0;
+    float* XS; float* Hs; float* HP; float* gates; float* S; float* CS;
+    const float* drop; float* HD;
+    float* hpart;                              // [nwg][32][ldcs]: head partials, rewritten every step
+    int* ctr; int* status;
+    int bs[MAXT];
+};
+
+__shared__ __align__(16) float w_part[8 * 4 * WROWS * 16];      // K-chunk partials [wave][r, z, n_i, n_h][row][unit]; head-partial staging
+__shared__ __align__(16) float w_red[4 * WROWS * 16];           // their sums
+__shared__ __align__(16) float w_hown[WS_MAXL * WROWS * 16];    // this workgroup's 16 units of every layer's hidden state
+__shared__ __align__(16) float w_stack[STACK_FLOATS];           // owned rows: [row k][image 0 / 1][DW4]
+__shared__ __align__(16) float w_act[64];                       // softmax(3) | tanh(W) of the row being updated
+__shared__ __align__(16) float w_top[64];                       // its new stack top, zero padded to ks
+__shared__ __align__(16) float w_pf[6 * 512];                   // cell operands requested ahead by LDS-DMA: [operand][cell thread][4]
+__shared__ int w_off[MAXT + 1];
+__shared__ int w_flag;
+
+__device__ __forceinline__ f32x2 ld2_sc1(const float* base, long long byte_off)
+{
+    return __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(make_rsrc(base), (int)byte_off, 0, CPOL_SC1));
+}
+__device__ __forceinline__ float ld1_sc1(const float* base, long long byte_off)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(make_rsrc(base), (int)byte_off, 0, CPOL_SC1));
+}
+
+// this lane's KK consecutive floats of an activation row (handed-off data: L1-bypassing loads)
+template <int KK>
+__device__ __forceinline__ void load_b(float (&b)[KK], const float* base, long long byte_off)
+{
+    if constexpr (KK % 4 == 0) {
+#pragma unroll
+        for (int x = 0; x < KK / 4; ++x) {
+            const f32x4 v = ld4_sc1(base, byte_off + 16 * x);
+            b[4 * x] = v[0]; b[4 * x + 1] = v[1]; b[4 * x + 2] = v[2]; b[4 * x + 3] = v[3];
+        }
+    } else if constexpr (KK == 2) {
+        const f32x2 v = ld2_sc1(base, byte_off);
+        b[0] = v[0]; b[1] = v[1];
+    } else {
+        static_assert(KK == 1, "K / 32 is 1, 2 or a multiple of 4");
+        b[0] = ld1_sc1(base, byte_off);
+    }
+}
+
+// acc[rt][0], acc[rt][1], acc[rt][NSEL] += W_q[16 units x K] . X[rows x K]^T over this wave's K chunk (K = 32 KK):
+// lane (n = lane & 15, g = lane >> 4) holds k = chunk + g KK + m of unit n (weights) and of batch row 16 rt + n (X)
+template <int KK, int NSEL, int NR>
+__device__ __forceinline__ void ws_product(f32x4 (&acc)[NR][4], const float (&w)[3][KK], const float* X, long long row0, int bt, int nrt,
+                                           int wave, int lane)
+{
+    const int n = lane & 15, g = lane >> 4;
+    constexpr int K = 32 * KK;
+    float b0[KK], b1[KK];
+    {
+        const int r = n < bt ? n : bt - 1;
+        load_b<KK>(b0, X, ((row0 + r) * K + wave * 4 * KK + g * KK) * 4);
+    }
+    if (NR > 1 && nrt > 1) {
+        const int r = 16 + n < bt ? 16 + n : bt - 1;
+        load_b<KK>(b1, X, ((row0 + r) * K + wave * 4 * KK + g * KK) * 4);
+    }
+#pragma unroll
+    for (int m = 0; m < KK; ++m) {
+        acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[0][m], b0[m], acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[1][m], b0[m], acc[0][1], 0, 0, 0);
+        acc[0][NSEL] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[2][m], b0[m], acc[0][NSEL], 0, 0, 0);
+    }
+    if (NR > 1 && nrt > 1) {
+#pragma unroll
+        for (int m = 0; m < KK; ++m) {
+            acc[NR - 1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[0][m], b1[m], acc[NR - 1][0], 0, 0, 0);
+            acc[NR - 1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[1][m], b1[m], acc[NR - 1][1], 0, 0, 0);
+            acc[NR - 1][NSEL] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[2][m], b1[m], acc[NR - 1][NSEL], 0, 0, 0);
+        }
+    }
+}
+
+// this lane's KK consecutive weights of gate row `grow` (a [rows x K] row-major matrix), K chunk of `wave`
+template <int KK>
+__device__ __forceinline__ void load_w(float (&w)[KK], const float* Wm, long long grow, int wave, int lane)
+{
+    const float* p = Wm + grow * (32 * KK) + wave * 4 * KK + (lane >> 4) * KK;
+#pragma unroll
+    for (int m = 0; m < KK; ++m) w[m] = p[m];
+}
+
+// ---- stack update of the rows this workgroup owns (rho = j + k nwg), for the stack ENTERING step t ----------------------
+// heads = the workgroups' partials added in workgroup order + bias -> softmax(3) / tanh(W); push / pop / no-op blend of
+// the row's stack image in LDS into its other image; the new row goes to S (for the backward), its top to XS (handed
+// to the group).
+__device__ __forceinline__ void ws_stack_phase(const WsArgs& a, int t, int j, int nwg, int ks)
+{
+    const int tid = threadIdx.x, bt = a.bs[t], ldcs = a.ldcs, W = a.W, DW = a.DW, DW4 = (DW + 3) & ~3, nout = 3 + W;
+    const long long base = w_off[t];
+    const bool vec = (DW & 3) == 0;
+    float* hp = w_part;                                // [nwg][ldcs]
+    for (int k = 0; j + k * nwg < bt; ++k) {           // workgroup-uniform
+        const int rho = j + k * nwg;
+        for (int e = tid; e < nwg * (ldcs >> 2); e += NTH) {
+            const int jj = e / (ldcs >> 2), o = (e - jj * (ldcs >> 2)) * 4;
+            st4(hp + jj * ldcs + o, ld4_sc1(a.hpart, (((long long)jj * WROWS + rho) * ldcs + o) * 4));
+        }
+        __syncthreads();
+        if (tid < ldcs) {
+            float v = 0.f;
+            for (int jj = 0; jj < nwg; ++jj) v += hp[jj * ldcs + tid];
+            w_act[tid] = tid < nout ? v + a.bcs[tid] : 0.f;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            const float p0 = w_act[0], p1 = w_act[1], p2 = w_act[2];
+            const float m = fmaxf(p0, fmaxf(p1, p2));
+            const float e0 = expf(p0 - m), e1 = expf(p1 - m), e2 = expf(p2 - m);
+            const float inv = 1.0f / (e0 + e1 + e2);
+            w_act[0] = e0 * inv; w_act[1] = e1 * inv; w_act[2] = e2 * inv;
+        } else if (tid >= 3 && tid < nout) w_act[tid] = tanhf(w_act[tid]);
+        __syncthreads();
+        const float a_push = w_act[0], a_pop = w_act[1], a_noop = w_act[2];
+        const float* sp = w_stack + (2 * k + ((t & 1) ^ 1)) * DW4;
+        float* sn = w_stack + (2 * k + (t & 1)) * DW4;
+        float* sg = a.S + (base + rho) * DW;
+        auto upd = [&](int e) {
+            const float up = e < W ? w_act[3 + e] : sp[e - W];
+            const float down = e + W < DW ? sp[e + W] : 0.f;
+            return a_noop * sp[e] + a_push * up + a_pop * down;
+        };
+        if (vec) {
+            for (int e4 = tid; e4 < (DW >> 2); e4 += NTH) {
+                f32x4 v;
+#pragma unroll
+                for (int x = 0; x < 4; ++x) v[x] = upd(4 * e4 + x);
+                st4(sn + 4 * e4, v);
+                st4(sg + 4 * e4, v);
+#pragma unroll
+                for (int x = 0; x < 4; ++x) if (4 * e4 + x < W) w_top[4 * e4 + x] = v[x];
+            }
+        } else {
+            for (int e = tid; e < DW; e += NTH) {
+                const float v = upd(e);
+                sn[e] = v;
+                sg[e] = v;
+                if (e < W) w_top[e] = v;
+            }
+        }
+        if (tid < nout) a.CS[(base + rho) * ldcs + tid] = w_act[tid];
+        __syncthreads();
+        if (tid < (ks >> 2)) st4_sc1(a.XS, ((base + rho) * ks + 4 * tid) * 4, ld4(w_top + 4 * tid));      // handed to the group
+        __syncthreads();
+    }
+}
+
+// ---- heads partial of this workgroup's 16 units of the top layer's hidden state (w_hown) ---------------------------
+//   hpart[j][row][o] = sum_c h[row][16 j + c] wcs_t[16 j + c][o]        wave = (row tile, 16-column block of the outputs)
+__device__ __forceinline__ void ws_heads_partial(const WsArgs& a, const float (&wc)[4], const float* hown, int j, int bt, int wave, int lane)
+{
+    const int n = lane & 15, g = lane >> 4, ot = wave & 3, rt = wave >> 2;
+    if (16 * ot < a.ldcs && 16 * rt < bt) {
+        const f32x4 hv = ld4(hown + (16 * rt + n) * 16 + 4 * g);
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int m = 0; m < 4; ++m) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wc[m], hv[m], acc, 0, 0, 0);
+        if (16 * rt + n < bt) st4_sc1(a.hpart, (((long long)j * WROWS + 16 * rt + n) * a.ldcs + 16 * ot + 4 * g) * 4, acc);
+    }
+}
+
+template <int H, int KS, int L, int NR>
+__global__ __launch_bounds__(NTH) void k_seq_fwd_ws(const WsArgs a)
+{
+    constexpr int KH = H / 32, KX = KS / 32, NWG = H / 16;
+    const int j = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n = lane & 15, g = lane >> 4;
+    const long long H3 = 3LL * H;
+    if (tid == 0) {
+        int s = 0;
+        for (int t = 0; t < a.T; ++t) { w_off[t] = s; s += a.bs[t]; }
+        w_off[a.T] = s;
+    }
+    // ---- the workgroup's weights: resident in registers from here on
+    float wh[L][3][KH], wi0[3][KX], wi[L > 1 ? L - 1 : 1][3][KH], wc[4];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        const long long grow = (long long)q * H + 16 * j + n;
+        load_w<KX>(wi0[q], a.wx0s, grow, wave, lane);
+#pragma unroll
+        for (int l = 0; l < L; ++l) load_w<KH>(wh[l][q], a.w_hh[l], grow, wave, lane);
+#pragma unroll
+        for (int l = 1; l < L; ++l) load_w<KH>(wi[l - 1][q], a.w_ih[l], grow, wave, lane);
+    }
+#pragma unroll
+    for (int m = 0; m < 4; ++m) wc[m] = 16 * (wave & 3) < a.ldcs ? a.wcs_t[(long long)(16 * j + 4 * g + m) * a.ldcs + 16 * (wave & 3) + n] : 0.f;
+    // own units of the initial hidden state; the owned rows' initial stacks; zero padding of the stack top
+    for (int e = tid; e < L * WROWS * 4; e += NTH) {
+        const int l = e / (WROWS * 4), row = (e >> 2) & (WROWS - 1), u4 = e & 3;
+        st4(w_hown + (l * WROWS + row) * 16 + 4 * u4,
+            row < a.B ? ld4(a.h0 + ((long long)l * a.B + row) * H + 16 * j + 4 * u4) : f32x4{0.f, 0.f, 0.f, 0.f});
+    }
+    {
+        const int DW4 = (a.DW + 3) & ~3;
+        for (int k = 0; j + k * NWG < a.B; ++k) {
+            float* img = w_stack + (2 * k + 1) * DW4;                 // the image step 0 reads
+            for (int e = tid; e < a.DW; e += NTH) img[e] = a.S0 ? a.S0[(long long)(j + k * NWG) * a.DW + e] : 0.f;
+        }
+    }
+    if (tid < 64) w_top[tid] = 0.f;
+    __syncthreads();
+    int* ctr = a.ctr;
+    // "step -1": the heads of the initial hidden state of the top layer
+    ws_heads_partial(a, wc, w_hown + (L - 1) * WROWS * 16, j, a.B, wave, lane);
+    group_signal(ctr + (L - 1) * CTR_STRIDE);
+
+    // epilogue of a layer: dump the K-chunk partials, sum them in wave order, GRU cell on the sums
+    auto epilogue = [&](f32x4 (&acc)[NR][4], int l, int t, int bt, int nrt) {
+        const long long base = w_off[t];
+#pragma unroll
+        for (int rt = 0; rt < NR; ++rt)
+            if (rt < nrt) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) st4(w_part + ((wave * 4 + q) * WROWS + 16 * rt + n) * 16 + 4 * g, acc[rt][q]);
+            }
+        __syncthreads();
+        {
+            const int q = tid >> 7, row = (tid >> 2) & 31, u4 = tid & 3;
+            if (row < bt) {
+                const float* p = w_part + (q * WROWS + row) * 16 + 4 * u4;
+                f32x4 v = ld4(p);
+#pragma unroll
+                for (int w = 1; w < 8; ++w) v += ld4(p + w * 4 * WROWS * 16);
+                st4(w_red + (q * WROWS + row) * 16 + 4 * u4, v);
+            }
+        }
+        wait_vmcnt<0>();                               // the cell threads' LDS-DMA requests (prefetch) have landed
+        __syncthreads();
+        if (tid < 4 * WROWS) {
+            const int row = tid >> 2, u4 = tid & 3, u = 16 * j + 4 * u4;
+            if (row < bt) {
+                f32x4 v[4], pf[6];
+#pragma unroll
+                for (int q = 0; q < 6; ++q) pf[q] = ld4(w_pf + q * 512 + 4 * tid);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) v[q] = ld4(w_red + (q * WROWS + row) * 16 + 4 * u4);
+                float* hl = w_hown + (l * WROWS + row) * 16 + 4 * u4;
+                const f32x4 hp = ld4(hl);
+                v[0] += pf[0] + pf[3];
+                v[1] += pf[1] + pf[4];
+                v[2] += pf[2];
+                v[3] += pf[5];
+                f32x4 rr, zz, nn, ho;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    rr[k] = sigmoidf_(v[0][k]);
+                    zz[k] = sigmoidf_(v[1][k]);
+                    nn[k] = tanhf(v[2][k] + rr[k] * v[3][k]);
+                    ho[k] = (1.0f - zz[k]) * nn[k] + zz[k] * hp[k];
+                }
+                const long long prow = (long long)l * a.NT + base + row;
+                st4_sc1(a.Hs, (prow * H + u) * 4, ho);                                       // handed to the group
+                if (a.drop && l < L - 1) st4_sc1(a.HD, (prow * H + u) * 4, ho * ld4(a.drop + prow * H + u));
+                st4(a.HP + prow * H + u, hp);
+                float* gt = a.gates + prow * 4 * H + u;
+                st4(gt, rr); st4(gt + H, zz); st4(gt + 2 * H, nn); st4(gt + 3 * H, v[3]);
+                st4(hl, ho);
+            }
+        }
+        __syncthreads();
+    };
+    // operands of the cell threads that depend on nothing handed off (per-token table row or input bias, recurrent bias):
+    // requested before the wait by LDS-DMA, so that no registers are held across the products
+    auto prefetch = [&](int l, int t, int bt) {
+        if (tid < 4 * WROWS && (tid >> 2) < bt) {
+            float* dst = w_pf + 256 * wave;
+            const int row = tid >> 2, u = 16 * j + 4 * (tid & 3);
+            const float* tp;
+            if (l == 0) {
+                const long long tok = a.tokens[w_off[t] + row];
+                tp = a.table + (tok < 0 ? 0 : (tok < a.V ? tok : a.V - 1)) * H3 + u;
+            } else tp = a.b_ih[l] + u;
+            const float* bp = a.b_hh[l] + u;
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                __builtin_amdgcn_global_load_lds(tp + q * H, PPK_LDS_PTR(dst + q * 512), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds(bp + q * H, PPK_LDS_PTR(dst + (3 + q) * 512), 16, 0, 0);
+            }
+        }
+    };
+
+    for (int t = 0; t < a.T; ++t) {
+        const int bt = a.bs[t], nrt = (bt + 15) >> 4;
+        const long long base = w_off[t], pbase = t > 0 ? w_off[t - 1] : 0;
+        f32x4 acc[NR][4];
+        auto zero = [&]() {
+#pragma unroll
+            for (int rt = 0; rt < NR; ++rt)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc[rt][q] = f32x4{0.f, 0.f, 0.f, 0.f};
+        };
+        auto hidden_product = [&](int l) {             // W_hh[l] . h_l(t-1): every unit of it was handed off one phase ago
+            if (t > 0) ws_product<KH, 3, NR>(acc, wh[l], a.Hs + (long long)l * a.NT * H, pbase, bt, nrt, wave, lane);
+            else ws_product<KH, 3, NR>(acc, wh[l], a.h0 + (long long)l * a.B * H, 0, bt, nrt, wave, lane);
+        };
+        zero();
+        if constexpr (L > 1) hidden_product(0);
+        // the stack entering this step: heads of the top layer's hidden state of the step before
+        if (!group_wait(ctr + (L - 1) * CTR_STRIDE, NWG * (t + 1), a.status, &w_flag)) return;
+        ws_stack_phase(a, t, j, NWG, KS);
+        group_signal(ctr + L * CTR_STRIDE);
+        if constexpr (L == 1) hidden_product(0);
+        // layer 0: + W_ih0[:, E:] . stack top, + table[token]
+        prefetch(0, t, bt);
+        if (!group_wait(ctr + L * CTR_STRIDE, NWG * (t + 1), a.status, &w_flag)) return;
+        ws_product<KX, 2, NR>(acc, wi0, a.XS, base, bt, nrt, wave, lane);
+        epilogue(acc, 0, t, bt, nrt);
+        if constexpr (L == 1) ws_heads_partial(a, wc, w_hown, j, bt, wave, lane);
+        group_signal(ctr);
+#pragma unroll
+        for (int l = 1; l < L; ++l) {
+            zero();
+            hidden_product(l);
+            prefetch(l, t, bt);
+            if (!group_wait(ctr + (l - 1) * CTR_STRIDE, NWG * (t + 1), a.status, &w_flag)) return;
+            ws_product<KH, 2, NR>(acc, wi[l - 1], (a.drop ? a.HD : a.Hs) + (long long)(l - 1) * a.NT * H, base, bt, nrt, wave, lane);
+            epilogue(acc, l, t, bt, nrt);
+            if (l == L - 1) ws_heads_partial(a, wc, w_hown + l * WROWS * 16, j, bt, wave, lane);
+            group_signal(ctr + l * CTR_STRIDE);
+        }
+    }
+}
+
+// [3+W, H] -> [H, ldcs] (zero padded)
+__global__ __launch_bounds__(256) void k_ws_wcs_transpose(const float* __restrict__ wcs, int nout, int H, int ldcs, float* __restrict__ out)
+{
+    const long long total = (long long)H * ldcs;
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+        const int k = (int)(e / ldcs), o = (int)(e - (long long)k * ldcs);
+        out[e] = o < nout ? wcs[(long long)o * H + k] : 0.f;
+    }
+}
+
+typedef void (*WsKernel)(const WsArgs);
+template <int H, int KS> WsKernel pick_l(int L, int nr)
+{
+    if (L == 1) return nr == 1 ? k_seq_fwd_ws<H, KS, 1, 1> : k_seq_fwd_ws<H, KS, 1, 2>;
+    if (L == 2) return nr == 1 ? k_seq_fwd_ws<H, KS, 2, 1> : k_seq_fwd_ws<H, KS, 2, 2>;
+    return nullptr;
+}
+// nr: 16-row tiles of the batch (1: at most 16 sequences, 2: at most 32)
+WsKernel pick_fwd(int H, int ks, int L, int nr)
+{
+    if (ks == 64) {
+        if (H == 512) return pick_l<512, 64>(L, nr);
+        if (H == 256) return pick_l<256, 64>(L, nr);
+        if (H == 128) return pick_l<128, 64>(L, nr);
+        if (H == 64) return pick_l<64, 64>(L, nr);
+        if (H == 32) return pick_l<32, 64>(L, nr);
+    } else if (ks == 32) {
+        if (H == 128) return pick_l<128, 32>(L, nr);
+        if (H == 64) return pick_l<64, 32>(L, nr);
+        if (H == 32) return pick_l<32, 32>(L, nr);
+    }
+    return nullptr;
+}
+
+}  // namespace
+
+namespace ppk {
+
+bool seq_fwd_ws_ok(int64_t T, int64_t B, int64_t NT, int64_t H, int64_t L, int64_t W, int64_t D, int64_t ks, int64_t ldcs)
+{
+    const int mode = seq_persist_mode(-2);
+    if (mode != 2 && mode != -1) return false;
+    if (T < 1 || T > MAXT || B < 1 || B > WROWS || L < 1 || L > WS_MAXL || NT >= (1LL << 24)) return false;
+    if (ldcs != (3 + W + 31) / 32 * 32 || ks != (W + 31) / 32 * 32 || ldcs > 64) return false;
+    if (!pick_fwd((int)H, (int)ks, (int)L, B > 16 ? 2 : 1)) return false;
+    const int64_t nwg = H / 16, nown = (WROWS + nwg - 1) / nwg, DW4 = (D * W + 3) / 4 * 4;
+    if (nown * 2 * DW4 > STACK_FLOATS) return false;
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return false;
+    return cus >= nwg;                                  // every workgroup resident at once, one per CU
+}
+
+int seq_fwd_ws(int64_t T, const int64_t* bs, int64_t B, int64_t NT, int64_t V, int64_t H, int64_t L, int64_t W, int64_t D,
+               const int64_t* tokens, const float* table, const float* wx0s, int64_t ks,
+               const float* const* w_ih, const float* const* w_hh, const float* const* b_ih, const float* const* b_hh,
+               const float* wcs, const float* bcs, const float* h0, const float* S0,
+               float* XS, float* Hs, float* HP, float* gates, float* S, float* CS, int64_t ldcs,
+               const float* drop, float* Hdrop, void* ws, size_t ws_bytes, hipStream_t stream)
+{
+    if (ws_bytes < seq_fwd_persist_ws_bytes(B, H, L, W)) PPK_FAIL(PPK_ERR_WS, "seq_fwd_ws: workspace too small");
+    WsKernel kern = pick_fwd((int)H, (int)ks, (int)L, B > 16 ? 2 : 1);
+    if (!kern) PPK_FAIL(PPK_ERR_UNSUP, "seq_fwd_ws: unsupported shape");
+    WsArgs a{};
+    a.T = (int)T; a.B = (int)B; a.W = (int)W; a.D = (int)D; a.V = (int)V; a.ldcs = (int)ldcs; a.DW = (int)(D * W);
+    a.NT = NT;
+    a.tokens = tokens; a.table = table; a.wx0s = wx0s;
+    for (int l = 0; l < (int)L; ++l) { a.w_ih[l] = w_ih[l]; a.w_hh[l] = w_hh[l]; a.b_ih[l] = b_ih[l]; a.b_hh[l] = b_hh[l]; }
+    a.bcs = bcs; a.h0 = h0; a.S0 = S0;
+    a.XS = XS; a.Hs = Hs; a.HP = HP; a.gates = gates; a.S = S; a.CS = CS;
+    a.drop = L > 1 ? drop : nullptr; a.HD = Hdrop;
+    for (int t = 0; t < (int)T; ++t) a.bs[t] = (int)bs[t];
+    // the same carve as the row-block persistent kernel with one group (seq_fwd_persist_ws_bytes covers it)
+    const int nwg = (int)(H / 16);
+    char* cur = (char*)ws;
+    float* wcs_t = (float*)ppk_carve(cur, sizeof(float) * (size_t)H * (size_t)ldcs);
+    const size_t nctr = (size_t)(L + 1) * CTR_STRIDE + 64;
+    int* ctr = (int*)ppk_carve(cur, sizeof(int) * nctr);
+    a.wcs_t = wcs_t; a.ctr = ctr; a.status = ctr + (size_t)(L + 1) * CTR_STRIDE;
+    a.hpart = (float*)ppk_carve(cur, sizeof(float) * (size_t)nwg * WROWS * (size_t)ldcs);
+    PPK_HIP(hipMemsetAsync(ctr, 0, sizeof(int) * nctr, stream));
+    k_ws_wcs_transpose<<<dim3((unsigned)std::min<int64_t>((H * ldcs + 255) / 256, 1024)), dim3(256), 0, stream>>>(wcs, (int)(3 + W), (int)H, (int)ldcs, wcs_t);
+    PPK_CHECK_LAUNCH("k_ws_wcs_transpose");
+    {
+        const double flops = 2.0 * (double)NT * 3.0 * (double)H * ((double)ks + (2.0 * (double)L - 1.0) * (double)H);
+        ProfScope prof(PK_SEQ_FWD, flops, stream);
+        kern<<<dim3((unsigned)nwg), dim3(NTH), 0, stream>>>(a);
+        PPK_CHECK_LAUNCH("k_seq_fwd_ws");
+    }
+    float* ptrs[5] = {Hs, CS, XS, S, a.drop ? Hdrop : nullptr};
+    const long long counts[5] = {(long long)L * NT * H, NT * ldcs, NT * ks, NT * D * W, (long long)(L - 1) * NT * H};
+    return seq_poison(a.status, ptrs, counts, 5, stream);
+}
+
+}  // namespace ppk

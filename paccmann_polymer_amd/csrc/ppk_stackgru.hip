@@ -247,6 +247,10 @@ int ppk_stackgru_seq_fwd(int64_t T, const int64_t* batch_sizes_host, int64_t B, 
     if (ws_bytes < ppk_stackgru_seq_fwd_workspace_bytes(B, H, L, W)) PPK_FAIL(PPK_ERR_WS, "stackgru_seq_fwd: workspace too small");
     if (drop && L > 1 && !Hdrop) PPK_FAIL(PPK_ERR_NULL, "stackgru_seq_fwd: dropout factors without Hdrop");
     if (L == 1) drop = nullptr;                       // nn.GRU applies dropout between layers only
+    // <= 32 rows: the whole time loop as one launch with the weights resident in registers (ppk_seq_ws.hip)
+    if (ppk::seq_fwd_ws_ok(T, B, NT, H, L, W, D, ks, ldcs))
+        return ppk::seq_fwd_ws(T, batch_sizes_host, B, NT, V, H, L, W, D, tokens, table, wx0s, ks, w_ih, w_hh, b_ih, b_hh,
+                               wcs, bcs, h0, S0, XS, Hs, HP, gates, S, CS, ldcs, drop, Hdrop, workspace, ws_bytes, stream);
     // the whole time loop as one persistent launch (ppk_seq_persist.hip) when the shape allows it
     if (ppk::seq_fwd_persist_ok(T, B, NT, H, L, W, D, ks, ldcs))
         return ppk::seq_fwd_persist(T, batch_sizes_host, B, NT, V, H, L, W, D, tokens, table, wx0s, ks, w_ih, w_hh, b_ih, b_hh,

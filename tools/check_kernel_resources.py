@@ -14,7 +14,7 @@ MIN_WAVES_PER_SIMD = 2     # 256-thread workgroups: 2 waves per SIMD = 2 workgro
 MAX_LDS = 80 * 1024        # two workgroups share the CU's 160 KiB
 
 
-def main(path, pattern):
+def main(path, pattern, max_lds=MAX_LDS):
     text = open(path, errors='replace').read()
     blocks = re.split(r'remark: Function Name: ', text)[1:]
     bad, seen = [], 0
@@ -30,13 +30,13 @@ def main(path, pattern):
         scratch, occ, lds, dyn = int(field('ScratchSize [bytes/lane]')), int(field('Occupancy [waves/SIMD]')), int(field('LDS Size [bytes/block]')), field('Dynamic Stack')
         line = f'{name}: scratch {scratch} B/lane, occupancy {occ} waves/SIMD, LDS {lds} B, dynamic stack {dyn}, VGPR spill {field("VGPRs Spill")}'
         print('  ' + line)
-        if scratch > MAX_SCRATCH or occ < MIN_WAVES_PER_SIMD or lds > MAX_LDS or dyn != 'False':
+        if scratch > MAX_SCRATCH or occ < MIN_WAVES_PER_SIMD or lds > max_lds or dyn != 'False':
             bad.append(line)
     if seen == 0:
         print(f'check_kernel_resources: no kernel matching {pattern!r} in {path}', file=sys.stderr)
         return 1
     if bad:
-        print('check_kernel_resources: FAILED (limits: scratch <= %d B/lane, occupancy >= %d waves/SIMD, LDS <= %d B, static stack)' % (MAX_SCRATCH, MIN_WAVES_PER_SIMD, MAX_LDS), file=sys.stderr)
+        print('check_kernel_resources: FAILED (limits: scratch <= %d B/lane, occupancy >= %d waves/SIMD, LDS <= %d B, static stack)' % (MAX_SCRATCH, MIN_WAVES_PER_SIMD, max_lds), file=sys.stderr)
         for l in bad:
             print('  ' + l, file=sys.stderr)
         return 1
@@ -44,4 +44,6 @@ def main(path, pattern):
 
 
 if __name__ == '__main__':
-    sys.exit(main(sys.argv[1], sys.argv[2] if len(sys.argv) > 2 else r'k_seq_(fwd|bwd)'))
+    # third argument: LDS limit in bytes (the small-batch weights-stationary kernels run ONE 512-thread workgroup per CU:
+    # 2 waves per SIMD with up to the CU's whole 160 KiB)
+    sys.exit(main(sys.argv[1], sys.argv[2] if len(sys.argv) > 2 else r'k_seq_(fwd|bwd)', int(sys.argv[3]) if len(sys.argv) > 3 else MAX_LDS))

@@ -76,6 +76,13 @@ int seq_fwd_ws(int64_t T, const int64_t* bs, int64_t B, int64_t NT, int64_t V, i
                float* XS, float* Hs, float* HP, float* gates, float* S, float* CS, int64_t ldcs,
                const float* drop, float* Hdrop, void* ws, size_t ws_bytes, hipStream_t stream);
 
+bool seq_bwd_ws_ok(int64_t T, int64_t B, int64_t NT, int64_t H, int64_t L, int64_t W, int64_t D, int64_t ks, int64_t ldcs);
+int seq_bwd_ws(int64_t T, const int64_t* bs, int64_t B, int64_t NT, int64_t H, int64_t L, int64_t W, int64_t D,
+               const float* const* w_ih_t, const float* const* w_hh_t, const float* wcs_t,
+               const float* HP, const float* gates, const float* S, const float* CS, int64_t ldcs,
+               const float* dHtop, float* dXS, int64_t ks, float* DGI, float* DGH, float* DCS, float* dh0,
+               const float* drop, void* ws, size_t ws_bytes, hipStream_t stream);
+
 // shared host helpers of the two persistent kernels (ppk_seq_persist.hip)
 int seq_poison(const int* status, float* const* ptrs, const long long* counts, int n, hipStream_t stream);
 int seq_capacity(const void* kernel, int slot);          // slot: 0 / 1 forward fp32 / bf16, 2 / 3 backward

@@ -385,6 +385,399 @@ __global__ __launch_bounds__(256) void k_ws_wcs_transpose(const float* __restric
     }
 }
 
+
+// =====================================================================================================================
+// Backward (the autograd graph the reference walks at experiments/chem_reactions/reactions_vae.py:94-95, loss.backward()),
+// same decomposition: workgroup j owns hidden units 16 j .. 16 j + 15 of the OUTPUT of every product and keeps its rows of
+// the TRANSPOSED matrices in registers: w_ih_t[l >= 1][u][3H], w_hh_t[l][u][3H] (48 registers each at H 512), its rows of
+// wcs_t and its 48 columns of the stack columns of W_ih0 (for the dXS partial).  Per step t (descending):
+//   TOP     accD = DCS_{t+1} . wcs_t[u]                        |wait stack backward of t + 1|
+//   l = L-1 .. 0:  gate backward of layer l on accD + carry (+ dHtop): dgi_l, dgh_l handed to the group
+//           l >= 1: |wait dgi_l| accD = dgi_l . W_ih[l] (-> dh_{l-1}), accC = dgh_l . W_hh[l] (-> carry_l)
+//   dXS partial over the workgroup's own 48 gate columns |signal| ; the owner of a row adds the partials, runs the
+//   stack-update backward on the row's gradient image in LDS (it never leaves the CU) and hands DCS_t to the group;
+//   carry_0 += dgh_0 . W_hh[0] runs behind that hand-off.
+// K order of the 3H contractions: [gate][unit], a wave takes units [w H/8, (w+1) H/8) of every gate, so the r and z
+// thirds (dgi == dgh) are loaded once.
+struct WsBwdArgs {
+    int T, B, W, D, ldcs, DW;
+    long long NT;
+    const float* w_ih_t[WS_MAXL]; const float* w_hh_t[WS_MAXL]; const float* wcs_t;
+    const float* HP; const float* gates; const float* S; const float* CS; const float* dHtop; const float* drop;
+    float* dXS; float* DGI; float* DGH; float* DCS; float* dh0;
+    float* xpart;                              // [nwg][32][ks]: dXS partials, rewritten every step
+    int* ctr; int* status;
+    int bs[MAXT];
+};
+
+constexpr int BSTACK_FLOATS = 15360;           // owned rows: two images of the stack gradient + the previous stack row
+__shared__ __align__(16) float w_carry[WS_MAXL * WROWS * 16];   // dh z of this workgroup's units (+ dgh . W_hh): the recurrent gradient
+__shared__ __align__(16) float w_g0[WROWS * 48];                // dgi_0 of this workgroup's units: [row][gate][unit]
+__shared__ __align__(16) float w_bstack[BSTACK_FLOATS];
+__shared__ __align__(16) float w_dc[64];
+__shared__ float w_rsum[8 * 4];
+
+template <int KK>
+__device__ __forceinline__ void mma_acc(f32x4& acc, const float (&w)[KK], const float (&b)[KK])
+{
+#pragma unroll
+    for (int m = 0; m < KK; ++m) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w[m], b[m], acc, 0, 0, 0);
+}
+
+// stack-update backward of the rows this workgroup owns at step t (k-th step of the launch); waits for the group's dXS
+// partials inside, behind the LDS-DMA requests for the previous stack rows
+__device__ __forceinline__ bool ws_stack_bwd(const WsBwdArgs& a, int t, int kstep, int j, int nwg, int ks, int* wctr, int wtarget)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int bt = a.bs[t], ldcs = a.ldcs, W = a.W, DW = a.DW, DW4 = (DW + 3) & ~3, nout = 3 + W, n4 = DW >> 2;
+    const long long base = w_off[t], pbase = t > 0 ? w_off[t - 1] : 0;
+    const bool vec = (DW & 3) == 0;
+    const int par = kstep & 1;
+    // previous stack rows of the owned rows (forward output: plain memory): requested before the wait
+    for (int k = 0; j + k * nwg < bt; ++k) {
+        float* spl = w_bstack + (3 * k + 2) * DW4;
+        const float* src = a.S + (pbase + j + k * nwg) * DW;
+        if (t == 0) { for (int e = tid; e < DW; e += NTH) spl[e] = 0.f; }
+        else if (vec) {
+            for (int pi = wave; pi * 64 < n4; pi += 8) {
+                const int e = pi * 64 + lane;
+                if (e < n4) __builtin_amdgcn_global_load_lds(src + 4 * e, PPK_LDS_PTR(spl + pi * 256), 16, 0, 0);
+            }
+        } else { for (int e = tid; e < DW; e += NTH) spl[e] = src[e]; }
+    }
+    if (!group_wait(wctr, wtarget, a.status, &w_flag)) return false;
+    wait_vmcnt<0>();
+    __syncthreads();
+    float* xp = w_part;                                // [nwg][ks]
+    for (int k = 0; j + k * nwg < bt; ++k) {           // workgroup-uniform
+        const int rho = j + k * nwg;
+        float* gin = w_bstack + (3 * k + (par ^ 1)) * DW4;
+        float* gout = w_bstack + (3 * k + par) * DW4;
+        const float* sp = w_bstack + (3 * k + 2) * DW4;
+        for (int e = tid; e < nwg * (ks >> 2); e += NTH) {
+            const int jj = e / (ks >> 2), o = (e - jj * (ks >> 2)) * 4;
+            st4(xp + jj * ks + o, ld4_sc1(a.xpart, (((long long)jj * WROWS + rho) * ks + o) * 4));
+        }
+        if (tid < ldcs) w_act[tid] = tid < nout ? a.CS[(base + rho) * ldcs + tid] : 0.f;
+        __syncthreads();
+        if (tid < ks) {
+            float v = 0.f;
+            for (int jj = 0; jj < nwg; ++jj) v += xp[jj * ks + tid];
+            a.dXS[(base + rho) * ks + tid] = v;
+            if (tid < W) gin[tid] += v;                // the stack top fed layer 0
+        }
+        __syncthreads();
+        const float a_push = w_act[0], a_pop = w_act[1], a_noop = w_act[2];
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+        for (int i = tid; i < DW; i += NTH) {
+            const float gv = gin[i];
+            const float up = i < W ? w_act[3 + i] : sp[i - W];
+            const float down = i + W < DW ? sp[i + W] : 0.f;
+            s0 = fmaf(gv, sp[i], s0);
+            s1 = fmaf(gv, up, s1);
+            s2 = fmaf(gv, down, s2);
+            float o = a_noop * gv;                     // gradient wrt the previous stack
+            if (i + W < DW) o = fmaf(a_push, gin[i + W], o);
+            if (i >= W) o = fmaf(a_pop, gin[i - W], o);
+            gout[i] = o;
+        }
+        s0 = ppk_wave_sum(s0); s1 = ppk_wave_sum(s1); s2 = ppk_wave_sum(s2);
+        if (lane == 0) { w_rsum[wave * 4] = s0; w_rsum[wave * 4 + 1] = s1; w_rsum[wave * 4 + 2] = s2; }
+        __syncthreads();
+        if (tid < ldcs) {
+            float t3[3];
+#pragma unroll
+            for (int q = 0; q < 3; ++q)
+                t3[q] = ((w_rsum[q] + w_rsum[4 + q]) + (w_rsum[8 + q] + w_rsum[12 + q])) + ((w_rsum[16 + q] + w_rsum[20 + q]) + (w_rsum[24 + q] + w_rsum[28 + q]));
+            const float s_noop = t3[0], s_push = t3[1], s_pop = t3[2];
+            const float dot = a_push * s_push + a_pop * s_pop + a_noop * s_noop;
+            float v = 0.f;
+            if (tid == 0) v = a_push * (s_push - dot);
+            else if (tid == 1) v = a_pop * (s_pop - dot);
+            else if (tid == 2) v = a_noop * (s_noop - dot);
+            else if (tid < nout) { const float sv = w_act[tid]; v = a_push * gin[tid - 3] * (1.0f - sv * sv); }
+            w_dc[tid] = v;
+        }
+        __syncthreads();
+        if (tid < (ldcs >> 2)) st4_sc1(a.DCS, ((base + rho) * ldcs + 4 * tid) * 4, ld4(w_dc + 4 * tid));      // handed to the group
+        __syncthreads();
+    }
+    return true;
+}
+
+template <int H, int KS, int L, int NR>
+__global__ __launch_bounds__(NTH) void k_seq_bwd_ws(const WsBwdArgs a)
+{
+    constexpr int KH = H / 32, NWG = H / 16, H3 = 3 * H;
+    const int j = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n = lane & 15, g = lane >> 4;
+    if (tid == 0) {
+        int s = 0;
+        for (int t = 0; t < a.T; ++t) { w_off[t] = s; s += a.bs[t]; }
+        w_off[a.T] = s;
+    }
+    // ---- the workgroup's rows of the transposed weights: resident in registers from here on
+    float wiT[L > 1 ? L - 1 : 1][3][KH], whT[L][3][KH], wc[2], wxa[3][4];
+    {
+        const long long urow = 16 * j + n;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+#pragma unroll
+            for (int l = 0; l < L; ++l) {
+                const float* p = a.w_hh_t[l] + urow * H3 + q * H + wave * 4 * KH + g * KH;
+#pragma unroll
+                for (int m = 0; m < KH; ++m) whT[l][q][m] = p[m];
+            }
+#pragma unroll
+            for (int l = 1; l < L; ++l) {
+                const float* p = a.w_ih_t[l] + urow * H3 + q * H + wave * 4 * KH + g * KH;
+#pragma unroll
+                for (int m = 0; m < KH; ++m) wiT[l - 1][q][m] = p[m];
+            }
+            // dXS partial: A[w][k], k = this workgroup's unit 4 g + mm of gate q; wave = (16-column block of w, row tile)
+            const int wcol = 16 * (wave & 3) + n;
+#pragma unroll
+            for (int mm = 0; mm < 4; ++mm) wxa[q][mm] = wcol < a.W ? a.w_ih_t[0][(long long)wcol * H3 + q * H + 16 * j + 4 * g + mm] : 0.f;
+        }
+        // TOP: K = ldcs split over the eight waves: ldcs / 32 values per lane
+        const int kc = a.ldcs >> 5;
+#pragma unroll
+        for (int m = 0; m < 2; ++m) wc[m] = m < kc ? a.wcs_t[urow * a.ldcs + wave * 4 * kc + g * kc + m] : 0.f;
+    }
+    for (int e = tid; e < WS_MAXL * WROWS * 16; e += NTH) w_carry[e] = 0.f;
+    for (int e = tid; e < BSTACK_FLOATS; e += NTH) w_bstack[e] = 0.f;
+    __syncthreads();
+    int* ctr = a.ctr;
+
+    // the gate threads' operands (saved gates, previous hidden, incoming top gradient): by LDS-DMA, ahead of the waits
+    auto prefetch = [&](int l, int t, int bt) {
+        if (tid < 4 * WROWS && (tid >> 2) < bt) {
+            float* dst = w_pf + 256 * wave;
+            const long long row = (long long)l * a.NT + w_off[t] + (tid >> 2);
+            const int u = 16 * j + 4 * (tid & 3);
+            const float* gt = a.gates + row * 4 * H + u;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) __builtin_amdgcn_global_load_lds(gt + q * H, PPK_LDS_PTR(dst + q * 512), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(a.HP + row * H + u, PPK_LDS_PTR(dst + 4 * 512), 16, 0, 0);
+            if (l == L - 1) __builtin_amdgcn_global_load_lds(a.dHtop + (w_off[t] + (tid >> 2)) * H + u, PPK_LDS_PTR(dst + 5 * 512), 16, 0, 0);
+        }
+    };
+    // sums of the K-chunk partials (slot 0: accD, slot 1: accC) into w_red
+    auto reduce = [&](f32x4 (&accD)[NR], f32x4 (&accC)[NR], int nslot, int nrt, int bt) {
+#pragma unroll
+        for (int rt = 0; rt < NR; ++rt)
+            if (rt < nrt) {
+                st4(w_part + ((wave * 2 + 0) * WROWS + 16 * rt + n) * 16 + 4 * g, accD[rt]);
+                if (nslot > 1) st4(w_part + ((wave * 2 + 1) * WROWS + 16 * rt + n) * 16 + 4 * g, accC[rt]);
+            }
+        __syncthreads();
+        {
+            const int q = tid >> 7, row = (tid >> 2) & 31, u4 = tid & 3;
+            if (q < nslot && row < bt) {
+                const float* p = w_part + (q * WROWS + row) * 16 + 4 * u4;
+                f32x4 v = ld4(p);
+#pragma unroll
+                for (int w = 1; w < 8; ++w) v += ld4(p + w * 2 * WROWS * 16);
+                st4(w_red + (q * WROWS + row) * 16 + 4 * u4, v);
+            }
+        }
+        wait_vmcnt<0>();
+        __syncthreads();
+    };
+
+    for (int t = a.T - 1, kstep = 0; t >= 0; --t, ++kstep) {
+        const int bt = a.bs[t], nn = t + 1 < a.T ? a.bs[t + 1] : 0, nrt = (bt + 15) >> 4, nrtn = (nn + 15) >> 4;
+        const long long base = w_off[t], nbase = w_off[t + 1];
+        f32x4 accD[NR], accC[NR];
+        auto zero = [&](f32x4 (&x)[NR]) {
+#pragma unroll
+            for (int rt = 0; rt < NR; ++rt) x[rt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        };
+        zero(accD);
+        zero(accC);
+        // ---- TOP: DCS_{t+1} . [W_c ; W_s] for the rows that were still active at t + 1
+        prefetch(L - 1, t, bt);
+        if (nn > 0) {
+            if (!group_wait(ctr + L * CTR_STRIDE, NWG * kstep, a.status, &w_flag)) return;
+            const int kc = a.ldcs >> 5;
+#pragma unroll
+            for (int rt = 0; rt < NR; ++rt)
+                if (rt < nrtn) {
+                    const int r = 16 * rt + n < nn ? 16 * rt + n : nn - 1;
+                    const long long bo = ((nbase + r) * a.ldcs + wave * 4 * kc + g * kc) * 4;
+                    if (kc == 2) {
+                        const f32x2 v = ld2_sc1(a.DCS, bo);
+                        accD[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wc[0], v[0], accD[rt], 0, 0, 0);
+                        accD[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wc[1], v[1], accD[rt], 0, 0, 0);
+                    } else {
+                        accD[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wc[0], ld1_sc1(a.DCS, bo), accD[rt], 0, 0, 0);
+                    }
+                }
+        }
+#pragma unroll
+        for (int l = L - 1; l >= 0; --l) {
+            // ---- gate backward of layer l: dh = accD (+ carry, + dHtop for the top layer)
+            reduce(accD, accC, l < L - 1 ? 2 : 1, nrt, bt);
+            if (tid < 4 * WROWS) {
+                const int row = tid >> 2, u4 = tid & 3, u = 16 * j + 4 * u4;
+                if (row < bt) {
+                    const f32x4 rr = ld4(w_pf + 4 * tid), zz = ld4(w_pf + 512 + 4 * tid), nv = ld4(w_pf + 2 * 512 + 4 * tid),
+                                hn = ld4(w_pf + 3 * 512 + 4 * tid), hp = ld4(w_pf + 4 * 512 + 4 * tid);
+                    f32x4 dsum = ld4(w_red + row * 16 + 4 * u4);
+                    if (l == L - 1) {
+                        if (row >= nn) dsum = f32x4{0.f, 0.f, 0.f, 0.f};         // no stack read this row's hidden at t + 1
+                        dsum += ld4(w_pf + 5 * 512 + 4 * tid);
+                    } else {
+                        // carry_{l+1} += dgh_{l+1} . W_hh[l+1]
+                        float* cp = w_carry + ((l + 1) * WROWS + row) * 16 + 4 * u4;
+                        st4(cp, ld4(cp) + ld4(w_red + (WROWS + row) * 16 + 4 * u4));
+                        // layer l + 1 read h_l * drop_l: its input gradient comes back through the same factors
+                        if (a.drop) dsum *= ld4(a.drop + ((long long)l * a.NT + base + row) * H + u);
+                    }
+                    float* cl = w_carry + (l * WROWS + row) * 16 + 4 * u4;
+                    const f32x4 dh = dsum + ld4(cl);
+                    f32x4 dn, dz, dr, dnr, c;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        dn[k] = dh[k] * (1.0f - zz[k]) * (1.0f - nv[k] * nv[k]);
+                        dz[k] = dh[k] * (hp[k] - nv[k]) * zz[k] * (1.0f - zz[k]);
+                        dr[k] = dn[k] * hn[k] * rr[k] * (1.0f - rr[k]);
+                        dnr[k] = dn[k] * rr[k];
+                        c[k] = dh[k] * zz[k];
+                    }
+                    const long long o = ((((long long)l * a.NT + base + row) * 3) * H + u) * 4;
+                    st4_sc1(a.DGI, o, dr); st4_sc1(a.DGI, o + 4LL * H, dz); st4_sc1(a.DGI, o + 8LL * H, dn);
+                    st4_sc1(a.DGH, o, dr); st4_sc1(a.DGH, o + 4LL * H, dz); st4_sc1(a.DGH, o + 8LL * H, dnr);
+                    st4(cl, c);
+                    if (l == 0) { st4(w_g0 + row * 48 + 4 * u4, dr); st4(w_g0 + row * 48 + 16 + 4 * u4, dz); st4(w_g0 + row * 48 + 32 + 4 * u4, dn); }
+                }
+            }
+            __syncthreads();
+            if (l == 0) break;
+            group_signal(ctr + l * CTR_STRIDE);
+            // ---- P_l: accD = dgi_l . W_ih[l] (-> dh_{l-1}), accC = dgh_l . W_hh[l] (-> carry_l)
+            prefetch(l - 1, t, bt);
+            zero(accD);
+            zero(accC);
+            if (!group_wait(ctr + l * CTR_STRIDE, NWG * (kstep + 1), a.status, &w_flag)) return;
+            {
+                const float* gi = a.DGI + (long long)l * a.NT * H3;
+                const float* gh = a.DGH + (long long)l * a.NT * H3;
+#pragma unroll
+                for (int rt = 0; rt < NR; ++rt)
+                    if (rt < nrt) {
+                        const int r = 16 * rt + n < bt ? 16 * rt + n : bt - 1;
+                        const long long bo = ((base + r) * H3 + wave * 4 * KH + g * KH) * 4;
+                        float b[KH];
+#pragma unroll
+                        for (int q = 0; q < 2; ++q) {                  // dr, dz: dgi == dgh
+                            load_b<KH>(b, gi, bo + 4LL * q * H);
+                            mma_acc<KH>(accD[rt], wiT[l - 1][q], b);
+                            mma_acc<KH>(accC[rt], whT[l][q], b);
+                        }
+                        load_b<KH>(b, gi, bo + 8LL * H);                // dn with W_ih
+                        mma_acc<KH>(accD[rt], wiT[l - 1][2], b);
+                        load_b<KH>(b, gh, bo + 8LL * H);                // dn r with W_hh
+                        mma_acc<KH>(accC[rt], whT[l][2], b);
+                    }
+            }
+        }
+        // ---- layer 0 is done: dXS partial over this workgroup's 48 gate columns, hand-off, stack backward, hand-off
+        {
+            const int ot = wave & 3, rt = wave >> 2;
+            if (16 * ot < KS && 16 * rt < bt) {
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int q = 0; q < 3; ++q) {
+                    const f32x4 gv = ld4(w_g0 + (16 * rt + n) * 48 + 16 * q + 4 * g);
+#pragma unroll
+                    for (int mm = 0; mm < 4; ++mm) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wxa[q][mm], gv[mm], acc, 0, 0, 0);
+                }
+                if (16 * rt + n < bt) st4_sc1(a.xpart, (((long long)j * WROWS + 16 * rt + n) * KS + 16 * ot + 4 * g) * 4, acc);
+            }
+        }
+        group_signal(ctr);
+        if (!ws_stack_bwd(a, t, kstep, j, NWG, KS, ctr, NWG * (kstep + 1))) return;
+        group_signal(ctr + L * CTR_STRIDE);
+        // ---- carry_0 += dgh_0 . W_hh[0]: only this workgroup's next step needs it — it fills the hand-off latency
+        {
+            zero(accC);
+#pragma unroll
+            for (int rt = 0; rt < NR; ++rt)
+                if (rt < nrt) {
+                    const int r = 16 * rt + n < bt ? 16 * rt + n : bt - 1;
+                    const long long bo = ((base + r) * H3 + wave * 4 * KH + g * KH) * 4;
+                    float b[KH];
+#pragma unroll
+                    for (int q = 0; q < 3; ++q) {
+                        load_b<KH>(b, a.DGH, bo + 4LL * q * H);
+                        mma_acc<KH>(accC[rt], whT[0][q], b);
+                    }
+                }
+            reduce(accC, accC, 1, nrt, bt);
+            if (tid < 4 * WROWS && (tid >> 2) < bt) {
+                float* cp = w_carry + (tid >> 2) * 16 + 4 * (tid & 3);
+                st4(cp, ld4(cp) + ld4(w_red + (tid >> 2) * 16 + 4 * (tid & 3)));
+            }
+            __syncthreads();
+        }
+    }
+    // the stack of step 0 read the INITIAL hidden state of the top layer: dh0[L-1] += DCS_0 . [W_c ; W_s]
+    {
+        if (!group_wait(ctr + L * CTR_STRIDE, NWG * a.T, a.status, &w_flag)) return;
+        f32x4 accD[NR];
+        const int kc = a.ldcs >> 5, nrt = (a.B + 15) >> 4;
+#pragma unroll
+        for (int rt = 0; rt < NR; ++rt) {
+            accD[rt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (rt < nrt) {
+                const int r = 16 * rt + n < a.B ? 16 * rt + n : a.B - 1;
+                const long long bo = (((long long)r) * a.ldcs + wave * 4 * kc + g * kc) * 4;
+                if (kc == 2) {
+                    const f32x2 v = ld2_sc1(a.DCS, bo);
+                    accD[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wc[0], v[0], accD[rt], 0, 0, 0);
+                    accD[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wc[1], v[1], accD[rt], 0, 0, 0);
+                } else {
+                    accD[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wc[0], ld1_sc1(a.DCS, bo), accD[rt], 0, 0, 0);
+                }
+            }
+        }
+        reduce(accD, accD, 1, nrt, a.B);
+        for (int e = tid; e < L * WROWS * 4; e += NTH) {
+            const int l = e / (WROWS * 4), row = (e >> 2) & (WROWS - 1), u4 = e & 3;
+            if (row < a.B) {
+                f32x4 v = ld4(w_carry + (l * WROWS + row) * 16 + 4 * u4);
+                if (l == L - 1) v += ld4(w_red + row * 16 + 4 * u4);
+                st4(a.dh0 + ((long long)l * a.B + row) * H + 16 * j + 4 * u4, v);
+            }
+        }
+    }
+}
+
+typedef void (*WsBwdKernel)(const WsBwdArgs);
+template <int H, int KS> WsBwdKernel pick_bl(int L, int nr)
+{
+    if (L == 1) return nr == 1 ? k_seq_bwd_ws<H, KS, 1, 1> : k_seq_bwd_ws<H, KS, 1, 2>;
+    if (L == 2) return nr == 1 ? k_seq_bwd_ws<H, KS, 2, 1> : k_seq_bwd_ws<H, KS, 2, 2>;
+    return nullptr;
+}
+WsBwdKernel pick_bwd(int H, int ks, int L, int nr)
+{
+    if (ks == 64) {
+        if (H == 512) return pick_bl<512, 64>(L, nr);
+        if (H == 256) return pick_bl<256, 64>(L, nr);
+        if (H == 128) return pick_bl<128, 64>(L, nr);
+        if (H == 64) return pick_bl<64, 64>(L, nr);
+        if (H == 32) return pick_bl<32, 64>(L, nr);
+    } else if (ks == 32) {
+        if (H == 128) return pick_bl<128, 32>(L, nr);
+        if (H == 64) return pick_bl<64, 32>(L, nr);
+        if (H == 32) return pick_bl<32, 32>(L, nr);
+    }
+    return nullptr;
+}
+
 typedef void (*WsKernel)(const WsArgs);
 template <int H, int KS> WsKernel pick_l(int L, int nr)
 {
@@ -465,6 +858,60 @@ int seq_fwd_ws(int64_t T, const int64_t* bs, int64_t B, int64_t NT, int64_t V, i
     }
     float* ptrs[5] = {Hs, CS, XS, S, a.drop ? Hdrop : nullptr};
     const long long counts[5] = {(long long)L * NT * H, NT * ldcs, NT * ks, NT * D * W, (long long)(L - 1) * NT * H};
+    return seq_poison(a.status, ptrs, counts, 5, stream);
+}
+
+bool seq_bwd_ws_ok(int64_t T, int64_t B, int64_t NT, int64_t H, int64_t L, int64_t W, int64_t D, int64_t ks, int64_t ldcs)
+{
+    const int mode = seq_persist_mode(-2);
+    if (mode != 2 && mode != -1) return false;
+    if (T < 1 || T > MAXT || B < 1 || B > WROWS || L < 1 || L > WS_MAXL || NT >= (1LL << 24)) return false;
+    if (ldcs != (3 + W + 31) / 32 * 32 || ks != (W + 31) / 32 * 32 || ldcs > 64) return false;
+    if (NT * 3 * H * 4 * L >= (1LL << 31)) return false;              // byte offsets of the buffer accesses into DGI / DGH
+    if (!pick_bwd((int)H, (int)ks, (int)L, B > 16 ? 2 : 1)) return false;
+    const int64_t nwg = H / 16, nown = (WROWS + nwg - 1) / nwg, DW4 = (D * W + 3) / 4 * 4;
+    if (nown * 3 * DW4 > BSTACK_FLOATS) return false;
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return false;
+    return cus >= nwg;
+}
+
+int seq_bwd_ws(int64_t T, const int64_t* bs, int64_t B, int64_t NT, int64_t H, int64_t L, int64_t W, int64_t D,
+               const float* const* w_ih_t, const float* const* w_hh_t, const float* wcs_t,
+               const float* HP, const float* gates, const float* S, const float* CS, int64_t ldcs,
+               const float* dHtop, float* dXS, int64_t ks, float* DGI, float* DGH, float* DCS, float* dh0,
+               const float* drop, void* ws, size_t ws_bytes, hipStream_t stream)
+{
+    if (ws_bytes < seq_bwd_persist_ws_bytes(B, H, L, W, D)) PPK_FAIL(PPK_ERR_WS, "seq_bwd_ws: workspace too small");
+    WsBwdKernel kern = pick_bwd((int)H, (int)ks, (int)L, B > 16 ? 2 : 1);
+    if (!kern) PPK_FAIL(PPK_ERR_UNSUP, "seq_bwd_ws: unsupported shape");
+    WsBwdArgs a{};
+    a.T = (int)T; a.B = (int)B; a.W = (int)W; a.D = (int)D; a.ldcs = (int)ldcs; a.DW = (int)(D * W);
+    a.NT = NT;
+    for (int l = 0; l < (int)L; ++l) { a.w_ih_t[l] = w_ih_t[l]; a.w_hh_t[l] = w_hh_t[l]; }
+    a.wcs_t = wcs_t;
+    a.HP = HP; a.gates = gates; a.S = S; a.CS = CS; a.dHtop = dHtop;
+    a.drop = L > 1 ? drop : nullptr;
+    a.dXS = dXS; a.DGI = DGI; a.DGH = DGH; a.DCS = DCS; a.dh0 = dh0;
+    for (int t = 0; t < (int)T; ++t) a.bs[t] = (int)bs[t];
+    // the carve of the row-block persistent backward with one group (its first block, the k-major copy of the stack
+    // columns of W_ih0, is not needed here: the registers are loaded from w_ih_t[0] directly)
+    const int nwg = (int)(H / 16);
+    char* cur = (char*)ws;
+    (void)ppk_carve(cur, sizeof(float) * (size_t)3 * H * ks);
+    const size_t nctr = (size_t)(L + 1) * CTR_STRIDE + 64;
+    int* ctr = (int*)ppk_carve(cur, sizeof(int) * nctr);
+    a.ctr = ctr; a.status = ctr + (size_t)(L + 1) * CTR_STRIDE;
+    a.xpart = (float*)ppk_carve(cur, sizeof(float) * (size_t)nwg * WROWS * (size_t)ks);
+    PPK_HIP(hipMemsetAsync(ctr, 0, sizeof(int) * nctr, stream));
+    {
+        const double flops = 2.0 * (double)NT * (double)H * (3.0 * (double)H * (2.0 * (double)L - 1.0) + (double)ldcs) + 2.0 * (double)NT * 3.0 * (double)H * (double)ks;
+        ProfScope prof(PK_SEQ_BWD, flops, stream);
+        kern<<<dim3((unsigned)nwg), dim3(NTH), 0, stream>>>(a);
+        PPK_CHECK_LAUNCH("k_seq_bwd_ws");
+    }
+    float* ptrs[5] = {dXS, DGI, DGH, DCS, dh0};
+    const long long counts[5] = {NT * ks, (long long)L * NT * 3 * H, (long long)L * NT * 3 * H, NT * ldcs, (long long)L * B * H};
     return seq_poison(a.status, ptrs, counts, 5, stream);
 }
 

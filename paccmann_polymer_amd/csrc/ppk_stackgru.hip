@@ -352,6 +352,10 @@ int ppk_stackgru_seq_bwd(int64_t T, const int64_t* batch_sizes_host, int64_t B, 
         PPK_FAIL(PPK_ERR_NULL, "stackgru_seq_bwd: null pointer");
     if (ws_bytes < ppk_stackgru_seq_bwd_workspace_bytes(B, H, L, W, D)) PPK_FAIL(PPK_ERR_WS, "stackgru_seq_bwd: workspace too small");
     if (L == 1) drop = nullptr;
+    // <= 32 rows: one launch with the transposed weights resident in registers (ppk_seq_ws.hip)
+    if (ppk::seq_bwd_ws_ok(T, B, NT, H, L, W, D, ks, ldcs))
+        return ppk::seq_bwd_ws(T, batch_sizes_host, B, NT, H, L, W, D, w_ih_t, w_hh_t, wcs_t, HP, gates, S, CS, ldcs,
+                               dHtop, dXS, ks, DGI, DGH, DCS, dh0, drop, workspace, ws_bytes, stream);
     // the whole time loop as one persistent launch (ppk_seq_persist_bwd.hip) when the shape allows it
     if (ppk::seq_bwd_persist_ok(T, B, NT, H, L, W, D, ks, ldcs))
         return ppk::seq_bwd_persist(T, batch_sizes_host, B, NT, H, L, W, D, w_ih_t, w_hh_t, wcs_t, HP, gates, S, CS, ldcs,

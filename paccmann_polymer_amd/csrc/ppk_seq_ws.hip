@@ -72,6 +72,37 @@ __device__ __forceinline__ float ld1_sc1(const float* base, long long byte_off)
     return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(make_rsrc(base), (int)byte_off, 0, CPOL_SC1));
 }
 
+// The wait of these kernels.  One 512-thread workgroup per CU, every handed-off byte written by 16-byte sc1 stores behind
+// group_signal (every wave drains, barrier, one agent-scope add) and read by sc1 buffer loads INTO REGISTERS after the
+// polling wave's barrier: MI355X_MICROARCH.md lists this form (one workgroup per CU, hipMalloc memory, sc1 poll of the
+// counter, sc1 loads of 4 / 8 / 16 bytes) as measured valid without the agent acquire, which costs 1.3 - 1.7 us per wait —
+// three per timestep here.  -DPPK_WS_ACQUIRE keeps it.  Polls are PPK_WS_POLL_SLEEP x 64 cycles apart (32 pollers on
+// three counter lines: the interval is latency, not contention) and bounded like group_wait's.
+#ifndef PPK_WS_POLL_SLEEP
+#define PPK_WS_POLL_SLEEP 2
+#endif
+__device__ __forceinline__ bool ws_wait(int* ctr, int target, int* status, volatile int* flag)
+{
+    if (threadIdx.x == 0) {
+        int ok = 0;
+        for (int it = 0; it < SPIN_LIMIT * (32 / PPK_WS_POLL_SLEEP); ++it) {
+            if (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target) { ok = 1; break; }
+            if ((it & 1023) == 1023 && __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
+            __builtin_amdgcn_s_sleep(PPK_WS_POLL_SLEEP);
+        }
+        if (!ok) __hip_atomic_store(status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#ifdef PPK_WS_ACQUIRE
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+        *flag = ok;
+    }
+    __syncthreads();
+    const bool ok = *flag != 0;
+    __syncthreads();
+    return ok;
+}
+
 // this lane's KK consecutive floats of an activation row (handed-off data: L1-bypassing loads)
 template <int KK>
 __device__ __forceinline__ void load_b(float (&b)[KK], const float* base, long long byte_off)
@@ -350,13 +381,13 @@ __global__ __launch_bounds__(NTH) void k_seq_fwd_ws(const WsArgs a)
         zero();
         if constexpr (L > 1) hidden_product(0);
         // the stack entering this step: heads of the top layer's hidden state of the step before
-        if (!group_wait(ctr + (L - 1) * CTR_STRIDE, NWG * (t + 1), a.status, &w_flag)) return;
+        if (!ws_wait(ctr + (L - 1) * CTR_STRIDE, NWG * (t + 1), a.status, &w_flag)) return;
         ws_stack_phase(a, t, j, NWG, KS);
         group_signal(ctr + L * CTR_STRIDE);
         if constexpr (L == 1) hidden_product(0);
         // layer 0: + W_ih0[:, E:] . stack top, + table[token]
         prefetch(0, t, bt);
-        if (!group_wait(ctr + L * CTR_STRIDE, NWG * (t + 1), a.status, &w_flag)) return;
+        if (!ws_wait(ctr + L * CTR_STRIDE, NWG * (t + 1), a.status, &w_flag)) return;
         ws_product<KX, 2, NR>(acc, wi0, a.XS, base, bt, nrt, wave, lane);
         epilogue(acc, 0, t, bt, nrt);
         if constexpr (L == 1) ws_heads_partial(a, wc, w_hown, j, bt, wave, lane);
@@ -366,7 +397,7 @@ __global__ __launch_bounds__(NTH) void k_seq_fwd_ws(const WsArgs a)
             zero();
             hidden_product(l);
             prefetch(l, t, bt);
-            if (!group_wait(ctr + (l - 1) * CTR_STRIDE, NWG * (t + 1), a.status, &w_flag)) return;
+            if (!ws_wait(ctr + (l - 1) * CTR_STRIDE, NWG * (t + 1), a.status, &w_flag)) return;
             ws_product<KH, 2, NR>(acc, wi[l - 1], (a.drop ? a.HD : a.Hs) + (long long)(l - 1) * a.NT * H, base, bt, nrt, wave, lane);
             epilogue(acc, l, t, bt, nrt);
             if (l == L - 1) ws_heads_partial(a, wc, w_hown + l * WROWS * 16, j, bt, wave, lane);
@@ -445,7 +476,7 @@ __device__ __forceinline__ bool ws_stack_bwd(const WsBwdArgs& a, int t, int kste
             }
         } else { for (int e = tid; e < DW; e += NTH) spl[e] = src[e]; }
     }
-    if (!group_wait(wctr, wtarget, a.status, &w_flag)) return false;
+    if (!ws_wait(wctr, wtarget, a.status, &w_flag)) return false;
     wait_vmcnt<0>();
     __syncthreads();
     float* xp = w_part;                                // [nwg][ks]
@@ -599,7 +630,7 @@ __global__ __launch_bounds__(NTH) void k_seq_bwd_ws(const WsBwdArgs a)
         // ---- TOP: DCS_{t+1} . [W_c ; W_s] for the rows that were still active at t + 1
         prefetch(L - 1, t, bt);
         if (nn > 0) {
-            if (!group_wait(ctr + L * CTR_STRIDE, NWG * kstep, a.status, &w_flag)) return;
+            if (!ws_wait(ctr + L * CTR_STRIDE, NWG * kstep, a.status, &w_flag)) return;
             const int kc = a.ldcs >> 5;
 #pragma unroll
             for (int rt = 0; rt < NR; ++rt)
@@ -660,7 +691,7 @@ __global__ __launch_bounds__(NTH) void k_seq_bwd_ws(const WsBwdArgs a)
             prefetch(l - 1, t, bt);
             zero(accD);
             zero(accC);
-            if (!group_wait(ctr + l * CTR_STRIDE, NWG * (kstep + 1), a.status, &w_flag)) return;
+            if (!ws_wait(ctr + l * CTR_STRIDE, NWG * (kstep + 1), a.status, &w_flag)) return;
             {
                 const float* gi = a.DGI + (long long)l * a.NT * H3;
                 const float* gh = a.DGH + (long long)l * a.NT * H3;
@@ -725,7 +756,7 @@ __global__ __launch_bounds__(NTH) void k_seq_bwd_ws(const WsBwdArgs a)
     }
     // the stack of step 0 read the INITIAL hidden state of the top layer: dh0[L-1] += DCS_0 . [W_c ; W_s]
     {
-        if (!group_wait(ctr + L * CTR_STRIDE, NWG * a.T, a.status, &w_flag)) return;
+        if (!ws_wait(ctr + L * CTR_STRIDE, NWG * a.T, a.status, &w_flag)) return;
         f32x4 accD[NR];
         const int kc = a.ldcs >> 5, nrt = (a.B + 15) >> 4;
 #pragma unroll

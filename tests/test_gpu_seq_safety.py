@@ -25,13 +25,14 @@ from torch.nn.utils.rnn import pack_sequence
 from paccmann_polymer_amd import _C
 from paccmann_polymer_amd import stack_gru_vae as M
 assert _C.LIB_PATH.endswith('libppk_spin.so'), _C.LIB_PATH
-assert _C.lib.ppk_seq_persist_mode(1) == 1
+MODE, NSEQ = int(sys.argv[1]), int(sys.argv[2])
+assert _C.lib.ppk_seq_persist_mode(MODE) == MODE
 params = dict(vocab_size=64, embedding_size=128, rnn_cell_size=512, n_layers=2, stack_width=50, stack_depth=50,
               latent_dim=256, dropout=0.0, padding_index=0, batch_size=1, batch_mode='packed')
 torch.manual_seed(0)
 vae = M.TeacherVAE(M.StackGRUEncoder(params), M.StackGRUDecoder(params)).cuda()
 rng = np.random.default_rng(0)
-seqs = [torch.tensor(np.concatenate([[2], rng.integers(4, 64, size=int(rng.integers(8, 20))), [3]])) for _ in range(96)]
+seqs = [torch.tensor(np.concatenate([[2], rng.integers(4, 64, size=int(rng.integers(8, 20))), [3]])) for _ in range(NSEQ)]
 enc = pack_sequence(seqs, enforce_sorted=False)
 tgt = pack_sequence([torch.cat([s[1:], torch.tensor([0])]) for s in seqs], enforce_sorted=False)
 mu, lv = vae.encode(enc)
@@ -46,11 +47,13 @@ print('GRAD_NAN', bool(torch.isnan(g).any()))
 '''
 
 
-def test_lost_handoff_poisons_every_output():
+@pytest.mark.parametrize('mode,nseq', [(1, 96), (2, 12), (2, 27)])
+def test_lost_handoff_poisons_every_output(mode, nseq):
+    """mode 1: the row-block persistent kernels; mode 2 with <= 32 sequences: the weights-stationary kernels (ppk_seq_ws.hip)."""
     lib = os.path.join(ROOT, 'paccmann_polymer_amd', 'libppk_spin.so')
     assert os.path.exists(lib), 'libppk_spin.so missing: run make -C paccmann_polymer_amd/csrc'
     env = dict(os.environ, PPK_LIB_PATH=lib, PYTHONPATH=ROOT + os.pathsep + os.environ.get('PYTHONPATH', ''))
-    r = subprocess.run([sys.executable, '-c', _TIMEOUT_CHILD], env=env, cwd=ROOT, capture_output=True, text=True, timeout=240)
+    r = subprocess.run([sys.executable, '-c', _TIMEOUT_CHILD, str(mode), str(nseq)], env=env, cwd=ROOT, capture_output=True, text=True, timeout=240)
     assert r.returncode == 0, r.stdout + r.stderr
     assert 'MU_NAN True' in r.stdout and 'LOSS_NAN True' in r.stdout and 'GRAD_NAN True' in r.stdout, r.stdout + r.stderr
 
@@ -81,13 +84,14 @@ def _seq_fwd_raw(lib, _C, T, bs, B, NT, V, H, L, W, D, tokens, table, wx0s, ks, 
     return Hs, S, CS, XS
 
 
-def test_wider_paddings_than_the_workspace_query_take_the_per_step_path():
+@pytest.mark.parametrize('mode,B', [(1, 70), (2, 20)])
+def test_wider_paddings_than_the_workspace_query_take_the_per_step_path(mode, B):
     """W = 20: minimal ks = ldcs = 32.  ks = ldcs = 64 passes check_dims; the persistent kernels would carve
     H * 64 and G * ntiles * 64 * 64 floats out of a workspace sized for 32 (advisor, round 2)."""
     from paccmann_polymer_amd import _C
     lib = _C.lib
     rng = np.random.default_rng(5)
-    V, H, L, W, D, B = 16, 64, 2, 20, 6, 70
+    V, H, L, W, D = 16, 64, 2, 20, 6
     lens = np.sort(rng.integers(3, 12, size=B))[::-1]
     T = int(lens[0])
     bs = [int((lens > t).sum()) for t in range(T)]
@@ -106,7 +110,7 @@ def test_wider_paddings_than_the_workspace_query_take_the_per_step_path():
     w0 = rnd(3 * H, W)
     out = {}
     try:
-        assert lib.ppk_seq_persist_mode(1) == 1
+        assert lib.ppk_seq_persist_mode(mode) == mode
         for pad in (32, 64):
             wx0s = torch.zeros(3 * H, pad, device='cuda')
             wx0s[:, :W] = w0
@@ -123,20 +127,20 @@ def test_wider_paddings_than_the_workspace_query_take_the_per_step_path():
     assert float((XS_a[:, :W] - XS_b[:, :W]).abs().max()) <= 2e-5
 
 
-def _seq_kernels_launched(H, B, T=6):
-    """Which sequence-kernel families one encoder forward + backward launches in AUTO mode (profiling table of the library)."""
+def _seq_kernels_launched(H, B, T=6, mode=-1, W=10):
+    """Which sequence-kernel families one encoder forward + backward launches (AUTO mode by default; profiling table of the library)."""
     from torch.nn.utils.rnn import pack_sequence
     from paccmann_polymer_amd import _C
     from paccmann_polymer_amd import stack_gru_vae as M
     lib = _C.lib
-    params = dict(vocab_size=32, embedding_size=32, rnn_cell_size=H, n_layers=2, stack_width=10, stack_depth=8,
+    params = dict(vocab_size=32, embedding_size=32, rnn_cell_size=H, n_layers=2, stack_width=W, stack_depth=8,
                   latent_dim=16, dropout=0.0, padding_index=0, batch_size=1, batch_mode='packed')
     torch.manual_seed(0)
     enc_net = M.StackGRUEncoder(params).cuda()
     rng = np.random.default_rng(B + H)
     seqs = [torch.tensor(np.concatenate([[2], rng.integers(4, 32, size=int(rng.integers(2, T))), [3]])) for _ in range(B)]
     enc = pack_sequence(seqs, enforce_sorted=False)
-    assert lib.ppk_seq_persist_mode(-1) == -1
+    assert lib.ppk_seq_persist_mode(mode) == mode
     lib.ppk_prof_enable(1)
     mu, lv = enc_net.encoder_train_step(enc)
     (mu.sum() + lv.sum()).backward()
@@ -145,6 +149,7 @@ def _seq_kernels_launched(H, B, T=6):
     nk = lib.ppk_prof_kind_count()
     ms, work, launches = (ctypes.c_double * nk)(), (ctypes.c_double * nk)(), (ctypes.c_int64 * nk)()
     lib.ppk_prof_collect(ms, work, launches)
+    lib.ppk_seq_persist_mode(-1)
     return {lib.ppk_prof_kind_name(k).decode() for k in range(nk) if launches[k]}
 
 
@@ -158,3 +163,17 @@ def test_auto_mode_picks_the_measured_faster_schedule(H, B, persistent):
     kinds = _seq_kernels_launched(H, B)
     assert ('k_seq_fwd' in kinds) == persistent, (H, B, sorted(kinds))
     assert ('k_seq_bwd' in kinds) == persistent, (H, B, sorted(kinds))
+
+
+@pytest.mark.parametrize('H,B,mode,single_launch', [
+    (512, 16, -1, True), (512, 32, -1, True), (512, 33, -1, False), (512, 16, 0, False), (512, 7, 2, True), (256, 21, -1, True),
+    (128, 9, 2, True), (96, 9, 2, False),
+])
+def test_small_batches_take_the_weights_stationary_kernels(H, B, mode, single_launch):
+    """Up to 32 sequences the whole time loop is ONE launch per pass with the weights resident in registers
+    (ppk_seq_ws.hip; reported under the k_seq_fwd / k_seq_bwd profiling kinds) in auto mode and mode 2; beyond 32 rows,
+    in mode 0 and at hidden sizes without an instantiation the per-step launches run."""
+    kinds = _seq_kernels_launched(H, B, mode=mode, W=10 if H <= 128 else 40)      # H >= 256 is instantiated for 64 stack columns only
+    assert ('k_seq_fwd' in kinds) == single_launch, (H, B, sorted(kinds))
+    assert ('k_seq_bwd' in kinds) == single_launch, (H, B, sorted(kinds))
+    assert ('k_stack_fwd' in kinds) != single_launch, (H, B, sorted(kinds))

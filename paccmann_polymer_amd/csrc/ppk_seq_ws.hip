@@ -50,6 +50,7 @@ struct WsArgs {
     const float* drop; float* HD;
     float* hpart;                              // [nwg][32][ldcs]: head partials, rewritten every step
     int* ctr; int* status;
+    long long* dbg;
     int bs[MAXT];
 };
 
@@ -57,11 +58,24 @@ __shared__ __align__(16) float w_part[8 * 4 * WROWS * 16];      // K-chunk parti
 __shared__ __align__(16) float w_red[4 * WROWS * 16];           // their sums
 __shared__ __align__(16) float w_hown[WS_MAXL * WROWS * 16];    // this workgroup's 16 units of every layer's hidden state
 __shared__ __align__(16) float w_stack[STACK_FLOATS];           // owned rows: [row k][image 0 / 1][DW4]
-__shared__ __align__(16) float w_act[64];                       // softmax(3) | tanh(W) of the row being updated
+__shared__ __align__(16) float w_act[16 * 64];                  // softmax(3) | tanh(W) of the owned rows (at most 16 per workgroup: H = 32)
 __shared__ __align__(16) float w_top[64];                       // its new stack top, zero padded to ks
 __shared__ __align__(16) float w_pf[6 * 512];                   // cell operands requested ahead by LDS-DMA: [operand][cell thread][4]
 __shared__ int w_off[MAXT + 1];
 __shared__ int w_flag;
+// PPK_WS_TIMING build (tools/ws_timing.py): thread 0 adds the shader-clock cycles of every phase into LDS slots
+#ifdef PPK_WS_TIMING
+__shared__ long long w_tacc[16];
+__shared__ long long w_tlast;
+long long* g_ws_dbg = nullptr;
+#define WSTAMP(id) do { if (threadIdx.x == 0) { const long long now_ = __builtin_readcyclecounter(); w_tacc[id] += now_ - w_tlast; w_tlast = now_; } } while (0)
+#define WSTAMP_INIT() do { if (threadIdx.x == 0) { for (int k_ = 0; k_ < 16; ++k_) w_tacc[k_] = 0; w_tlast = __builtin_readcyclecounter(); } } while (0)
+#define WSTAMP_DUMP(dbg, j) do { if (threadIdx.x == 0 && (dbg)) for (int k_ = 0; k_ < 16; ++k_) (dbg)[(long long)(j) * 16 + k_] = w_tacc[k_]; } while (0)
+#else
+#define WSTAMP(id) do { } while (0)
+#define WSTAMP_INIT() do { } while (0)
+#define WSTAMP_DUMP(dbg, j) do { } while (0)
+#endif
 
 __device__ __forceinline__ f32x2 ld2_sc1(const float* base, long long byte_off)
 {
@@ -155,6 +169,18 @@ __device__ __forceinline__ void ws_product(f32x4 (&acc)[NR][4], const float (&w)
     }
 }
 
+// the three gate tiles of one row tile: acc[0], acc[1], acc[NSEL] += W_q . b
+template <int KK, int NSEL>
+__device__ __forceinline__ void mma_gates(f32x4 (&acc)[4], const float (&w)[3][KK], const float (&b)[KK])
+{
+#pragma unroll
+    for (int m = 0; m < KK; ++m) {
+        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[0][m], b[m], acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[1][m], b[m], acc[1], 0, 0, 0);
+        acc[NSEL] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[2][m], b[m], acc[NSEL], 0, 0, 0);
+    }
+}
+
 // this lane's KK consecutive weights of gate row `grow` (a [rows x K] row-major matrix), K chunk of `wave`
 template <int KK>
 __device__ __forceinline__ void load_w(float (&w)[KK], const float* Wm, long long grow, int wave, int lane)
@@ -165,17 +191,18 @@ __device__ __forceinline__ void load_w(float (&w)[KK], const float* Wm, long lon
 }
 
 // ---- stack update of the rows this workgroup owns (rho = j + k nwg), for the stack ENTERING step t ----------------------
-// heads = the workgroups' partials added in workgroup order + bias -> softmax(3) / tanh(W); push / pop / no-op blend of
-// the row's stack image in LDS into its other image; the new row goes to S (for the backward), its top to XS (handed
-// to the group).
-__device__ __forceinline__ void ws_stack_phase(const WsArgs& a, int t, int j, int nwg, int ks)
+// In two parts around the hand-off.  ws_stack_top: heads = the workgroups' partials added in workgroup order + bias ->
+// softmax(3) / tanh(W), then ONLY the new stack top (W elements) -> XS, handed to the group.  ws_stack_rest, behind the
+// signal: the push / pop / no-op blend of the whole row's image in LDS into its other image, the new row to S and the
+// activations to CS (both read by later kernels only) — off the group's critical path.
+__device__ __forceinline__ void ws_stack_top(const WsArgs& a, int t, int j, int nwg, int ks)
 {
     const int tid = threadIdx.x, bt = a.bs[t], ldcs = a.ldcs, W = a.W, DW = a.DW, DW4 = (DW + 3) & ~3, nout = 3 + W;
     const long long base = w_off[t];
-    const bool vec = (DW & 3) == 0;
     float* hp = w_part;                                // [nwg][ldcs]
     for (int k = 0; j + k * nwg < bt; ++k) {           // workgroup-uniform
         const int rho = j + k * nwg;
+        float* act = w_act + 64 * k;
         for (int e = tid; e < nwg * (ldcs >> 2); e += NTH) {
             const int jj = e / (ldcs >> 2), o = (e - jj * (ldcs >> 2)) * 4;
             st4(hp + jj * ldcs + o, ld4_sc1(a.hpart, (((long long)jj * WROWS + rho) * ldcs + o) * 4));
@@ -184,23 +211,41 @@ __device__ __forceinline__ void ws_stack_phase(const WsArgs& a, int t, int j, in
         if (tid < ldcs) {
             float v = 0.f;
             for (int jj = 0; jj < nwg; ++jj) v += hp[jj * ldcs + tid];
-            w_act[tid] = tid < nout ? v + a.bcs[tid] : 0.f;
+            act[tid] = tid < nout ? v + a.bcs[tid] : 0.f;
         }
         __syncthreads();
         if (tid == 0) {
-            const float p0 = w_act[0], p1 = w_act[1], p2 = w_act[2];
+            const float p0 = act[0], p1 = act[1], p2 = act[2];
             const float m = fmaxf(p0, fmaxf(p1, p2));
             const float e0 = expf(p0 - m), e1 = expf(p1 - m), e2 = expf(p2 - m);
             const float inv = 1.0f / (e0 + e1 + e2);
-            w_act[0] = e0 * inv; w_act[1] = e1 * inv; w_act[2] = e2 * inv;
-        } else if (tid >= 3 && tid < nout) w_act[tid] = tanhf(w_act[tid]);
+            act[0] = e0 * inv; act[1] = e1 * inv; act[2] = e2 * inv;
+        } else if (tid >= 3 && tid < nout) act[tid] = tanhf(act[tid]);
         __syncthreads();
-        const float a_push = w_act[0], a_pop = w_act[1], a_noop = w_act[2];
+        if (tid < ks) {
+            const float* sp = w_stack + (2 * k + ((t & 1) ^ 1)) * DW4;
+            float v = 0.f;
+            if (tid < W) v = act[2] * sp[tid] + act[0] * act[3 + tid] + act[1] * (tid + W < DW ? sp[tid + W] : 0.f);
+            w_top[tid] = v;
+        }
+        __syncthreads();
+        if (tid < (ks >> 2)) st4_sc1(a.XS, ((base + rho) * ks + 4 * tid) * 4, ld4(w_top + 4 * tid));      // handed to the group
+    }
+}
+__device__ __forceinline__ void ws_stack_rest(const WsArgs& a, int t, int j, int nwg)
+{
+    const int tid = threadIdx.x, bt = a.bs[t], ldcs = a.ldcs, W = a.W, DW = a.DW, DW4 = (DW + 3) & ~3, nout = 3 + W;
+    const long long base = w_off[t];
+    const bool vec = (DW & 3) == 0;
+    for (int k = 0; j + k * nwg < bt; ++k) {           // workgroup-uniform
+        const int rho = j + k * nwg;
+        const float* act = w_act + 64 * k;
+        const float a_push = act[0], a_pop = act[1], a_noop = act[2];
         const float* sp = w_stack + (2 * k + ((t & 1) ^ 1)) * DW4;
         float* sn = w_stack + (2 * k + (t & 1)) * DW4;
         float* sg = a.S + (base + rho) * DW;
         auto upd = [&](int e) {
-            const float up = e < W ? w_act[3 + e] : sp[e - W];
+            const float up = e < W ? act[3 + e] : sp[e - W];
             const float down = e + W < DW ? sp[e + W] : 0.f;
             return a_noop * sp[e] + a_push * up + a_pop * down;
         };
@@ -211,21 +256,15 @@ __device__ __forceinline__ void ws_stack_phase(const WsArgs& a, int t, int j, in
                 for (int x = 0; x < 4; ++x) v[x] = upd(4 * e4 + x);
                 st4(sn + 4 * e4, v);
                 st4(sg + 4 * e4, v);
-#pragma unroll
-                for (int x = 0; x < 4; ++x) if (4 * e4 + x < W) w_top[4 * e4 + x] = v[x];
             }
         } else {
             for (int e = tid; e < DW; e += NTH) {
                 const float v = upd(e);
                 sn[e] = v;
                 sg[e] = v;
-                if (e < W) w_top[e] = v;
             }
         }
-        if (tid < nout) a.CS[(base + rho) * ldcs + tid] = w_act[tid];
-        __syncthreads();
-        if (tid < (ks >> 2)) st4_sc1(a.XS, ((base + rho) * ks + 4 * tid) * 4, ld4(w_top + 4 * tid));      // handed to the group
-        __syncthreads();
+        if (tid < nout) a.CS[(base + rho) * ldcs + tid] = act[tid];
     }
 }
 
@@ -284,12 +323,16 @@ __global__ __launch_bounds__(NTH) void k_seq_fwd_ws(const WsArgs a)
     }
     if (tid < 64) w_top[tid] = 0.f;
     __syncthreads();
+    WSTAMP_INIT();
     int* ctr = a.ctr;
     // "step -1": the heads of the initial hidden state of the top layer
     ws_heads_partial(a, wc, w_hown + (L - 1) * WROWS * 16, j, a.B, wave, lane);
     group_signal(ctr + (L - 1) * CTR_STRIDE);
 
-    // epilogue of a layer: dump the K-chunk partials, sum them in wave order, GRU cell on the sums
+    // epilogue of a layer: dump the K-chunk partials, sum them in wave order, GRU cell on the sums (one element per
+    // thread: the transcendental functions are the long part), then ONLY the handed-off stores; what later kernels read
+    // (HP, gates) is stored by epilogue_tail behind the signal
+    float* cellv = w_part;                             // [hp, r, z, n, hn][32][16]: the partials are consumed by then
     auto epilogue = [&](f32x4 (&acc)[NR][4], int l, int t, int bt, int nrt) {
         const long long base = w_off[t];
 #pragma unroll
@@ -309,40 +352,38 @@ __global__ __launch_bounds__(NTH) void k_seq_fwd_ws(const WsArgs a)
                 st4(w_red + (q * WROWS + row) * 16 + 4 * u4, v);
             }
         }
-        wait_vmcnt<0>();                               // the cell threads' LDS-DMA requests (prefetch) have landed
+        wait_vmcnt<0>();                               // the LDS-DMA requests of prefetch() have landed
         __syncthreads();
-        if (tid < 4 * WROWS) {
-            const int row = tid >> 2, u4 = tid & 3, u = 16 * j + 4 * u4;
-            if (row < bt) {
-                f32x4 v[4], pf[6];
-#pragma unroll
-                for (int q = 0; q < 6; ++q) pf[q] = ld4(w_pf + q * 512 + 4 * tid);
-#pragma unroll
-                for (int q = 0; q < 4; ++q) v[q] = ld4(w_red + (q * WROWS + row) * 16 + 4 * u4);
-                float* hl = w_hown + (l * WROWS + row) * 16 + 4 * u4;
-                const f32x4 hp = ld4(hl);
-                v[0] += pf[0] + pf[3];
-                v[1] += pf[1] + pf[4];
-                v[2] += pf[2];
-                v[3] += pf[5];
-                f32x4 rr, zz, nn, ho;
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    rr[k] = sigmoidf_(v[0][k]);
-                    zz[k] = sigmoidf_(v[1][k]);
-                    nn[k] = tanhf(v[2][k] + rr[k] * v[3][k]);
-                    ho[k] = (1.0f - zz[k]) * nn[k] + zz[k] * hp[k];
-                }
-                const long long prow = (long long)l * a.NT + base + row;
-                st4_sc1(a.Hs, (prow * H + u) * 4, ho);                                       // handed to the group
-                if (a.drop && l < L - 1) st4_sc1(a.HD, (prow * H + u) * 4, ho * ld4(a.drop + prow * H + u));
-                st4(a.HP + prow * H + u, hp);
-                float* gt = a.gates + prow * 4 * H + u;
-                st4(gt, rr); st4(gt + H, zz); st4(gt + 2 * H, nn); st4(gt + 3 * H, v[3]);
-                st4(hl, ho);
-            }
+        if ((tid >> 4) < bt) {
+            const int e = tid;                         // row * 16 + unit
+            const float v0 = w_red[e] + (w_pf[e] + w_pf[3 * 512 + e]);
+            const float v1 = w_red[512 + e] + (w_pf[512 + e] + w_pf[4 * 512 + e]);
+            const float v2 = w_red[1024 + e] + w_pf[1024 + e];
+            const float v3 = w_red[1536 + e] + w_pf[5 * 512 + e];
+            const float hp = w_hown[l * 512 + e];
+            const float rr = sigmoidf_(v0), zz = sigmoidf_(v1);
+            const float nn = tanhf(v2 + rr * v3);
+            w_hown[l * 512 + e] = (1.0f - zz) * nn + zz * hp;
+            cellv[e] = hp; cellv[512 + e] = rr; cellv[1024 + e] = zz; cellv[1536 + e] = nn; cellv[2048 + e] = v3;
         }
         __syncthreads();
+        if (tid < 4 * WROWS && (tid >> 2) < bt) {
+            const long long prow = (long long)l * a.NT + base + (tid >> 2);
+            const int u = 16 * j + 4 * (tid & 3);
+            const f32x4 ho = ld4(w_hown + l * 512 + 4 * tid);
+            st4_sc1(a.Hs, (prow * H + u) * 4, ho);                                           // handed to the group
+            if (a.drop && l < L - 1) st4_sc1(a.HD, (prow * H + u) * 4, ho * ld4(a.drop + prow * H + u));
+        }
+    };
+    auto epilogue_tail = [&](int l, int t, int bt) {
+        if (tid < 4 * WROWS && (tid >> 2) < bt) {
+            const long long prow = (long long)l * a.NT + w_off[t] + (tid >> 2);
+            const int u = 16 * j + 4 * (tid & 3);
+            st4(a.HP + prow * H + u, ld4(cellv + 4 * tid));
+            float* gt = a.gates + prow * 4 * H + u;
+            st4(gt, ld4(cellv + 512 + 4 * tid)); st4(gt + H, ld4(cellv + 1024 + 4 * tid));
+            st4(gt + 2 * H, ld4(cellv + 1536 + 4 * tid)); st4(gt + 3 * H, ld4(cellv + 2048 + 4 * tid));
+        }
     };
     // operands of the cell threads that depend on nothing handed off (per-token table row or input bias, recurrent bias):
     // requested before the wait by LDS-DMA, so that no registers are held across the products
@@ -364,6 +405,71 @@ __global__ __launch_bounds__(NTH) void k_seq_fwd_ws(const WsArgs a)
         }
     };
 
+    // ---- two layers, at most 16 rows, no dropout: the operands of the products that need nothing new never wait for
+    // memory.  W_hh0 . h_0(t) (for step t + 1) reuses the registers that fed W_ih1 . h_0(t); the rows of h_1(t-1) are
+    // requested together with the stack tops and used behind the next signal.  (With two row tiles the extra 32 - 48
+    // registers spill; with dropout layer 1 reads the dropped-out copy, not h_0.)
+    if constexpr (L == 2 && NR == 1) {
+        if (!a.drop) {
+            f32x4 acc[1][4];
+            float bx[KX], bh[KH], b[KH];
+            auto zero1 = [&]() {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc[0][q] = f32x4{0.f, 0.f, 0.f, 0.f};
+            };
+            const long long lo = (wave * 4 * KH + g * KH) * 4;             // this lane's piece of a K = H row, bytes
+            zero1();
+            load_b<KH>(b, a.h0, ((long long)(n < a.B ? n : a.B - 1) * H) * 4 + lo);
+            mma_gates<KH, 3>(acc[0], wh[0], b);
+            for (int t = 0; t < a.T; ++t) {
+                const int bt = a.bs[t];
+                const long long base = w_off[t], pbase = t > 0 ? w_off[t - 1] : 0;
+                const int rx = n < bt ? n : bt - 1;
+                WSTAMP(0);
+                if (!ws_wait(ctr + CTR_STRIDE, NWG * (t + 1), a.status, &w_flag)) return;
+                WSTAMP(1);
+                ws_stack_top(a, t, j, NWG, KS);
+                WSTAMP(2);
+                group_signal(ctr + 2 * CTR_STRIDE);
+                WSTAMP(3);
+                ws_stack_rest(a, t, j, NWG);
+                prefetch(0, t, bt);
+                if (!ws_wait(ctr + 2 * CTR_STRIDE, NWG * (t + 1), a.status, &w_flag)) return;
+                WSTAMP(4);
+                load_b<KX>(bx, a.XS, ((base + rx) * KS + wave * 4 * KX + g * KX) * 4);
+                if (t > 0) load_b<KH>(bh, a.Hs + a.NT * H, (pbase + rx) * H * 4 + lo);
+                else load_b<KH>(bh, a.h0 + (long long)a.B * H, (long long)rx * H * 4 + lo);
+                mma_gates<KX, 2>(acc[0], wi0, bx);
+                WSTAMP(5);
+                epilogue(acc, 0, t, bt, 1);
+                WSTAMP(6);
+                group_signal(ctr);
+                WSTAMP(7);
+                epilogue_tail(0, t, bt);
+                zero1();
+                mma_gates<KH, 3>(acc[0], wh[1], bh);
+                prefetch(1, t, bt);
+                WSTAMP(8);
+                if (!ws_wait(ctr, NWG * (t + 1), a.status, &w_flag)) return;
+                WSTAMP(9);
+                load_b<KH>(b, a.Hs, (base + rx) * H * 4 + lo);
+                mma_gates<KH, 2>(acc[0], wi[0], b);
+                WSTAMP(10);
+                epilogue(acc, 1, t, bt, 1);
+                WSTAMP(11);
+                ws_heads_partial(a, wc, w_hown + WROWS * 16, j, bt, wave, lane);
+                WSTAMP(12);
+                group_signal(ctr + CTR_STRIDE);
+                WSTAMP(13);
+                epilogue_tail(1, t, bt);
+                zero1();
+                if (t + 1 < a.T) mma_gates<KH, 3>(acc[0], wh[0], b);     // rows of step t + 1 are a prefix of this step's
+            }
+            WSTAMP_DUMP(a.dbg, j);
+            return;
+        }
+    }
+
     for (int t = 0; t < a.T; ++t) {
         const int bt = a.bs[t], nrt = (bt + 15) >> 4;
         const long long base = w_off[t], pbase = t > 0 ? w_off[t - 1] : 0;
@@ -380,30 +486,48 @@ __global__ __launch_bounds__(NTH) void k_seq_fwd_ws(const WsArgs a)
         };
         zero();
         if constexpr (L > 1) hidden_product(0);
+        WSTAMP(0);
         // the stack entering this step: heads of the top layer's hidden state of the step before
         if (!ws_wait(ctr + (L - 1) * CTR_STRIDE, NWG * (t + 1), a.status, &w_flag)) return;
-        ws_stack_phase(a, t, j, NWG, KS);
+        WSTAMP(1);
+        ws_stack_top(a, t, j, NWG, KS);
+        WSTAMP(2);
         group_signal(ctr + L * CTR_STRIDE);
+        WSTAMP(3);
+        ws_stack_rest(a, t, j, NWG);
         if constexpr (L == 1) hidden_product(0);
         // layer 0: + W_ih0[:, E:] . stack top, + table[token]
         prefetch(0, t, bt);
         if (!ws_wait(ctr + L * CTR_STRIDE, NWG * (t + 1), a.status, &w_flag)) return;
+        WSTAMP(4);
         ws_product<KX, 2, NR>(acc, wi0, a.XS, base, bt, nrt, wave, lane);
+        WSTAMP(5);
         epilogue(acc, 0, t, bt, nrt);
         if constexpr (L == 1) ws_heads_partial(a, wc, w_hown, j, bt, wave, lane);
+        WSTAMP(6);
         group_signal(ctr);
+        WSTAMP(7);
+        epilogue_tail(0, t, bt);
 #pragma unroll
         for (int l = 1; l < L; ++l) {
             zero();
             hidden_product(l);
             prefetch(l, t, bt);
+            WSTAMP(8);
             if (!ws_wait(ctr + (l - 1) * CTR_STRIDE, NWG * (t + 1), a.status, &w_flag)) return;
+            WSTAMP(9);
             ws_product<KH, 2, NR>(acc, wi[l - 1], (a.drop ? a.HD : a.Hs) + (long long)(l - 1) * a.NT * H, base, bt, nrt, wave, lane);
+            WSTAMP(10);
             epilogue(acc, l, t, bt, nrt);
+            WSTAMP(11);
             if (l == L - 1) ws_heads_partial(a, wc, w_hown + l * WROWS * 16, j, bt, wave, lane);
+            WSTAMP(12);
             group_signal(ctr + l * CTR_STRIDE);
+            WSTAMP(13);
+            epilogue_tail(l, t, bt);
         }
     }
+    WSTAMP_DUMP(a.dbg, j);
 }
 
 // [3+W, H] -> [H, ldcs] (zero padded)
@@ -438,15 +562,17 @@ struct WsBwdArgs {
     float* dXS; float* DGI; float* DGH; float* DCS; float* dh0;
     float* xpart;                              // [nwg][32][ks]: dXS partials, rewritten every step
     int* ctr; int* status;
+    long long* dbg;
     int bs[MAXT];
 };
 
 constexpr int BSTACK_FLOATS = 15360;           // owned rows: two images of the stack gradient + the previous stack row
+__shared__ __align__(16) float w_bpart[8 * 2 * WROWS * 16];      // K-chunk partials [wave][accD, accC][row][unit]; dXS-partial staging
 __shared__ __align__(16) float w_carry[WS_MAXL * WROWS * 16];   // dh z of this workgroup's units (+ dgh . W_hh): the recurrent gradient
 __shared__ __align__(16) float w_g0[WROWS * 48];                // dgi_0 of this workgroup's units: [row][gate][unit]
 __shared__ __align__(16) float w_bstack[BSTACK_FLOATS];
 __shared__ __align__(16) float w_dc[64];
-__shared__ float w_rsum[8 * 4];
+__shared__ float w_rsum[(16 * 8 + 2) * 4];                    // dot-product partials: [owned row][wave][3] before the wait, [wave 0 / 1][3] behind it
 
 template <int KK>
 __device__ __forceinline__ void mma_acc(f32x4& acc, const float (&w)[KK], const float (&b)[KK])
@@ -455,16 +581,19 @@ __device__ __forceinline__ void mma_acc(f32x4& acc, const float (&w)[KK], const 
     for (int m = 0; m < KK; ++m) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w[m], b[m], acc, 0, 0, 0);
 }
 
-// stack-update backward of the rows this workgroup owns at step t (k-th step of the launch); waits for the group's dXS
-// partials inside, behind the LDS-DMA requests for the previous stack rows
-__device__ __forceinline__ bool ws_stack_bwd(const WsBwdArgs& a, int t, int kstep, int j, int nwg, int ks, int* wctr, int wtarget)
+// stack-update backward of the rows this workgroup owns at step t (k-th step of the launch).  Only the first W
+// elements of the row's incoming gradient change with dXS (the stack top fed layer 0), so everything else — the three dot
+// products over the elements i >= W and the outgoing gradient of the elements i >= 2W — is computed BEFORE the wait for
+// the group's dXS partials, next to the LDS-DMA requests for the previous stack rows; behind the wait only 2W elements
+// and the DCS row remain.
+__device__ __forceinline__ void ws_stack_bwd_pre(const WsBwdArgs& a, int t, int kstep, int j, int nwg)
 {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int bt = a.bs[t], ldcs = a.ldcs, W = a.W, DW = a.DW, DW4 = (DW + 3) & ~3, nout = 3 + W, n4 = DW >> 2;
     const long long base = w_off[t], pbase = t > 0 ? w_off[t - 1] : 0;
     const bool vec = (DW & 3) == 0;
     const int par = kstep & 1;
-    // previous stack rows of the owned rows (forward output: plain memory): requested before the wait
+    // previous stack rows of the owned rows (forward output: plain memory) and their saved activations
     for (int k = 0; j + k * nwg < bt; ++k) {
         float* spl = w_bstack + (3 * k + 2) * DW4;
         const float* src = a.S + (pbase + j + k * nwg) * DW;
@@ -475,21 +604,51 @@ __device__ __forceinline__ bool ws_stack_bwd(const WsBwdArgs& a, int t, int kste
                 if (e < n4) __builtin_amdgcn_global_load_lds(src + 4 * e, PPK_LDS_PTR(spl + pi * 256), 16, 0, 0);
             }
         } else { for (int e = tid; e < DW; e += NTH) spl[e] = src[e]; }
+        if (tid < ldcs) w_act[64 * k + tid] = tid < nout ? a.CS[(base + j + k * nwg) * ldcs + tid] : 0.f;
     }
-    if (!ws_wait(wctr, wtarget, a.status, &w_flag)) return false;
     wait_vmcnt<0>();
     __syncthreads();
-    float* xp = w_part;                                // [nwg][ks]
+    for (int k = 0; j + k * nwg < bt; ++k) {
+        const float* gin = w_bstack + (3 * k + (par ^ 1)) * DW4;
+        float* gout = w_bstack + (3 * k + par) * DW4;
+        const float* sp = w_bstack + (3 * k + 2) * DW4;
+        const float* act = w_act + 64 * k;
+        const float a_push = act[0], a_pop = act[1], a_noop = act[2];
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+        for (int i = W + tid; i < DW; i += NTH) {
+            const float gv = gin[i];
+            const float down = i + W < DW ? sp[i + W] : 0.f;
+            s0 = fmaf(gv, sp[i], s0);
+            s1 = fmaf(gv, sp[i - W], s1);
+            s2 = fmaf(gv, down, s2);
+            if (i >= 2 * W) {
+                float o = a_noop * gv;                 // gradient wrt the previous stack
+                if (i + W < DW) o = fmaf(a_push, gin[i + W], o);
+                o = fmaf(a_pop, gin[i - W], o);
+                gout[i] = o;
+            }
+        }
+        s0 = ppk_wave_sum(s0); s1 = ppk_wave_sum(s1); s2 = ppk_wave_sum(s2);
+        if (lane == 0) { float* r = w_rsum + (k * 8 + wave) * 4; r[0] = s0; r[1] = s1; r[2] = s2; }
+    }
+}
+__device__ __forceinline__ void ws_stack_bwd_post(const WsBwdArgs& a, int t, int kstep, int j, int nwg, int ks)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int bt = a.bs[t], ldcs = a.ldcs, W = a.W, DW = a.DW, DW4 = (DW + 3) & ~3, nout = 3 + W;
+    const long long base = w_off[t];
+    const int par = kstep & 1;
+    float* xp = w_bpart;                                // [nwg][ks]
     for (int k = 0; j + k * nwg < bt; ++k) {           // workgroup-uniform
         const int rho = j + k * nwg;
         float* gin = w_bstack + (3 * k + (par ^ 1)) * DW4;
         float* gout = w_bstack + (3 * k + par) * DW4;
         const float* sp = w_bstack + (3 * k + 2) * DW4;
+        const float* act = w_act + 64 * k;
         for (int e = tid; e < nwg * (ks >> 2); e += NTH) {
             const int jj = e / (ks >> 2), o = (e - jj * (ks >> 2)) * 4;
             st4(xp + jj * ks + o, ld4_sc1(a.xpart, (((long long)jj * WROWS + rho) * ks + o) * 4));
         }
-        if (tid < ldcs) w_act[tid] = tid < nout ? a.CS[(base + rho) * ldcs + tid] : 0.f;
         __syncthreads();
         if (tid < ks) {
             float v = 0.f;
@@ -498,42 +657,46 @@ __device__ __forceinline__ bool ws_stack_bwd(const WsBwdArgs& a, int t, int kste
             if (tid < W) gin[tid] += v;                // the stack top fed layer 0
         }
         __syncthreads();
-        const float a_push = w_act[0], a_pop = w_act[1], a_noop = w_act[2];
-        float s0 = 0.f, s1 = 0.f, s2 = 0.f;
-        for (int i = tid; i < DW; i += NTH) {
-            const float gv = gin[i];
-            const float up = i < W ? w_act[3 + i] : sp[i - W];
-            const float down = i + W < DW ? sp[i + W] : 0.f;
-            s0 = fmaf(gv, sp[i], s0);
-            s1 = fmaf(gv, up, s1);
-            s2 = fmaf(gv, down, s2);
-            float o = a_noop * gv;                     // gradient wrt the previous stack
-            if (i + W < DW) o = fmaf(a_push, gin[i + W], o);
-            if (i >= W) o = fmaf(a_pop, gin[i - W], o);
-            gout[i] = o;
+        const float a_push = act[0], a_pop = act[1], a_noop = act[2];
+        if (tid < 128) {                               // the 2W <= 128 elements that depend on dXS (waves 0 and 1)
+            float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+            const int i = tid;
+            if (i < 2 * W && i < DW) {
+                const float gv = gin[i];
+                if (i < W) {
+                    const float down = i + W < DW ? sp[i + W] : 0.f;
+                    s0 = gv * sp[i];
+                    s1 = gv * act[3 + i];
+                    s2 = gv * down;
+                }
+                float o = a_noop * gv;
+                if (i + W < DW) o = fmaf(a_push, gin[i + W], o);
+                if (i >= W) o = fmaf(a_pop, gin[i - W], o);
+                gout[i] = o;
+            }
+            s0 = ppk_wave_sum(s0); s1 = ppk_wave_sum(s1); s2 = ppk_wave_sum(s2);
+            if (lane == 0) { float* r = w_rsum + (16 * 8 + wave) * 4; r[0] = s0; r[1] = s1; r[2] = s2; }
         }
-        s0 = ppk_wave_sum(s0); s1 = ppk_wave_sum(s1); s2 = ppk_wave_sum(s2);
-        if (lane == 0) { w_rsum[wave * 4] = s0; w_rsum[wave * 4 + 1] = s1; w_rsum[wave * 4 + 2] = s2; }
         __syncthreads();
         if (tid < ldcs) {
             float t3[3];
+            const float* r = w_rsum + k * 8 * 4;
+            const float* h = w_rsum + 16 * 8 * 4;
 #pragma unroll
             for (int q = 0; q < 3; ++q)
-                t3[q] = ((w_rsum[q] + w_rsum[4 + q]) + (w_rsum[8 + q] + w_rsum[12 + q])) + ((w_rsum[16 + q] + w_rsum[20 + q]) + (w_rsum[24 + q] + w_rsum[28 + q]));
+                t3[q] = (((r[q] + r[4 + q]) + (r[8 + q] + r[12 + q])) + ((r[16 + q] + r[20 + q]) + (r[24 + q] + r[28 + q]))) + (h[q] + h[4 + q]);
             const float s_noop = t3[0], s_push = t3[1], s_pop = t3[2];
             const float dot = a_push * s_push + a_pop * s_pop + a_noop * s_noop;
             float v = 0.f;
             if (tid == 0) v = a_push * (s_push - dot);
             else if (tid == 1) v = a_pop * (s_pop - dot);
             else if (tid == 2) v = a_noop * (s_noop - dot);
-            else if (tid < nout) { const float sv = w_act[tid]; v = a_push * gin[tid - 3] * (1.0f - sv * sv); }
+            else if (tid < nout) { const float sv = act[tid]; v = a_push * gin[tid - 3] * (1.0f - sv * sv); }
             w_dc[tid] = v;
         }
         __syncthreads();
         if (tid < (ldcs >> 2)) st4_sc1(a.DCS, ((base + rho) * ldcs + 4 * tid) * 4, ld4(w_dc + 4 * tid));      // handed to the group
-        __syncthreads();
     }
-    return true;
 }
 
 template <int H, int KS, int L, int NR>
@@ -579,6 +742,7 @@ __global__ __launch_bounds__(NTH) void k_seq_bwd_ws(const WsBwdArgs a)
     for (int e = tid; e < WS_MAXL * WROWS * 16; e += NTH) w_carry[e] = 0.f;
     for (int e = tid; e < BSTACK_FLOATS; e += NTH) w_bstack[e] = 0.f;
     __syncthreads();
+    WSTAMP_INIT();
     int* ctr = a.ctr;
 
     // the gate threads' operands (saved gates, previous hidden, incoming top gradient): by LDS-DMA, ahead of the waits
@@ -599,14 +763,14 @@ __global__ __launch_bounds__(NTH) void k_seq_bwd_ws(const WsBwdArgs a)
 #pragma unroll
         for (int rt = 0; rt < NR; ++rt)
             if (rt < nrt) {
-                st4(w_part + ((wave * 2 + 0) * WROWS + 16 * rt + n) * 16 + 4 * g, accD[rt]);
-                if (nslot > 1) st4(w_part + ((wave * 2 + 1) * WROWS + 16 * rt + n) * 16 + 4 * g, accC[rt]);
+                st4(w_bpart + ((wave * 2 + 0) * WROWS + 16 * rt + n) * 16 + 4 * g, accD[rt]);
+                if (nslot > 1) st4(w_bpart + ((wave * 2 + 1) * WROWS + 16 * rt + n) * 16 + 4 * g, accC[rt]);
             }
         __syncthreads();
         {
             const int q = tid >> 7, row = (tid >> 2) & 31, u4 = tid & 3;
             if (q < nslot && row < bt) {
-                const float* p = w_part + (q * WROWS + row) * 16 + 4 * u4;
+                const float* p = w_bpart + (q * WROWS + row) * 16 + 4 * u4;
                 f32x4 v = ld4(p);
 #pragma unroll
                 for (int w = 1; w < 8; ++w) v += ld4(p + w * 2 * WROWS * 16);
@@ -631,6 +795,7 @@ __global__ __launch_bounds__(NTH) void k_seq_bwd_ws(const WsBwdArgs a)
         prefetch(L - 1, t, bt);
         if (nn > 0) {
             if (!ws_wait(ctr + L * CTR_STRIDE, NWG * kstep, a.status, &w_flag)) return;
+            WSTAMP(0);
             const int kc = a.ldcs >> 5;
 #pragma unroll
             for (int rt = 0; rt < NR; ++rt)
@@ -649,7 +814,9 @@ __global__ __launch_bounds__(NTH) void k_seq_bwd_ws(const WsBwdArgs a)
 #pragma unroll
         for (int l = L - 1; l >= 0; --l) {
             // ---- gate backward of layer l: dh = accD (+ carry, + dHtop for the top layer)
+            WSTAMP(1);
             reduce(accD, accC, l < L - 1 ? 2 : 1, nrt, bt);
+            WSTAMP(2);
             if (tid < 4 * WROWS) {
                 const int row = tid >> 2, u4 = tid & 3, u = 16 * j + 4 * u4;
                 if (row < bt) {
@@ -685,13 +852,16 @@ __global__ __launch_bounds__(NTH) void k_seq_bwd_ws(const WsBwdArgs a)
                 }
             }
             __syncthreads();
+            WSTAMP(3);
             if (l == 0) break;
             group_signal(ctr + l * CTR_STRIDE);
+            WSTAMP(4);
             // ---- P_l: accD = dgi_l . W_ih[l] (-> dh_{l-1}), accC = dgh_l . W_hh[l] (-> carry_l)
             prefetch(l - 1, t, bt);
             zero(accD);
             zero(accC);
             if (!ws_wait(ctr + l * CTR_STRIDE, NWG * (kstep + 1), a.status, &w_flag)) return;
+            WSTAMP(5);
             {
                 const float* gi = a.DGI + (long long)l * a.NT * H3;
                 const float* gh = a.DGH + (long long)l * a.NT * H3;
@@ -700,17 +870,18 @@ __global__ __launch_bounds__(NTH) void k_seq_bwd_ws(const WsBwdArgs a)
                     if (rt < nrt) {
                         const int r = 16 * rt + n < bt ? 16 * rt + n : bt - 1;
                         const long long bo = ((base + r) * H3 + wave * 4 * KH + g * KH) * 4;
-                        float b[KH];
-#pragma unroll
-                        for (int q = 0; q < 2; ++q) {                  // dr, dz: dgi == dgh
-                            load_b<KH>(b, gi, bo + 4LL * q * H);
-                            mma_acc<KH>(accD[rt], wiT[l - 1][q], b);
-                            mma_acc<KH>(accC[rt], whT[l][q], b);
-                        }
-                        load_b<KH>(b, gi, bo + 8LL * H);                // dn with W_ih
-                        mma_acc<KH>(accD[rt], wiT[l - 1][2], b);
-                        load_b<KH>(b, gh, bo + 8LL * H);                // dn r with W_hh
-                        mma_acc<KH>(accC[rt], whT[l][2], b);
+                        // every load of the row tile goes out before its first MFMA: one memory round trip, not four
+                        float b0[KH], b1[KH], b2[KH], b3[KH];
+                        load_b<KH>(b0, gi, bo);                          // dr
+                        load_b<KH>(b1, gi, bo + 4LL * H);                // dz          (dgi == dgh for both)
+                        load_b<KH>(b2, gi, bo + 8LL * H);                // dn with W_ih
+                        load_b<KH>(b3, gh, bo + 8LL * H);                // dn r with W_hh
+                        mma_acc<KH>(accD[rt], wiT[l - 1][0], b0);
+                        mma_acc<KH>(accC[rt], whT[l][0], b0);
+                        mma_acc<KH>(accD[rt], wiT[l - 1][1], b1);
+                        mma_acc<KH>(accC[rt], whT[l][1], b1);
+                        mma_acc<KH>(accD[rt], wiT[l - 1][2], b2);
+                        mma_acc<KH>(accC[rt], whT[l][2], b3);
                     }
             }
         }
@@ -728,10 +899,19 @@ __global__ __launch_bounds__(NTH) void k_seq_bwd_ws(const WsBwdArgs a)
                 if (16 * rt + n < bt) st4_sc1(a.xpart, (((long long)j * WROWS + 16 * rt + n) * KS + 16 * ot + 4 * g) * 4, acc);
             }
         }
+        WSTAMP(6);
         group_signal(ctr);
-        if (!ws_stack_bwd(a, t, kstep, j, NWG, KS, ctr, NWG * (kstep + 1))) return;
+        WSTAMP(7);
+        ws_stack_bwd_pre(a, t, kstep, j, NWG);
+        if (!ws_wait(ctr, NWG * (kstep + 1), a.status, &w_flag)) return;
+        WSTAMP(11);
+        ws_stack_bwd_post(a, t, kstep, j, NWG, KS);
+        WSTAMP(8);
         group_signal(ctr + L * CTR_STRIDE);
-        // ---- carry_0 += dgh_0 . W_hh[0]: only this workgroup's next step needs it — it fills the hand-off latency
+        WSTAMP(9);
+        // ---- carry_0 += dgh_0 . W_hh[0]: only this workgroup's next step needs it — it fills the DCS hand-off.  (Requesting
+        // its 96 KB of rows before the owners finish their stack rows put those loads in front of the owners' dXS partials:
+        // 44.4 -> 48.6 k cycles per timestep, not kept.)
         {
             zero(accC);
 #pragma unroll
@@ -739,12 +919,13 @@ __global__ __launch_bounds__(NTH) void k_seq_bwd_ws(const WsBwdArgs a)
                 if (rt < nrt) {
                     const int r = 16 * rt + n < bt ? 16 * rt + n : bt - 1;
                     const long long bo = ((base + r) * H3 + wave * 4 * KH + g * KH) * 4;
-                    float b[KH];
-#pragma unroll
-                    for (int q = 0; q < 3; ++q) {
-                        load_b<KH>(b, a.DGH, bo + 4LL * q * H);
-                        mma_acc<KH>(accC[rt], whT[0][q], b);
-                    }
+                    float b0[KH], b1[KH], b2[KH];
+                    load_b<KH>(b0, a.DGH, bo);
+                    load_b<KH>(b1, a.DGH, bo + 4LL * H);
+                    load_b<KH>(b2, a.DGH, bo + 8LL * H);
+                    mma_acc<KH>(accC[rt], whT[0][0], b0);
+                    mma_acc<KH>(accC[rt], whT[0][1], b1);
+                    mma_acc<KH>(accC[rt], whT[0][2], b2);
                 }
             reduce(accC, accC, 1, nrt, bt);
             if (tid < 4 * WROWS && (tid >> 2) < bt) {
@@ -753,6 +934,7 @@ __global__ __launch_bounds__(NTH) void k_seq_bwd_ws(const WsBwdArgs a)
             }
             __syncthreads();
         }
+        WSTAMP(10);
     }
     // the stack of step 0 read the INITIAL hidden state of the top layer: dh0[L-1] += DCS_0 . [W_c ; W_s]
     {
@@ -784,6 +966,7 @@ __global__ __launch_bounds__(NTH) void k_seq_bwd_ws(const WsBwdArgs a)
             }
         }
     }
+    WSTAMP_DUMP(a.dbg, j);
 }
 
 typedef void (*WsBwdKernel)(const WsBwdArgs);
@@ -869,6 +1052,9 @@ int seq_fwd_ws(int64_t T, const int64_t* bs, int64_t B, int64_t NT, int64_t V, i
     a.bcs = bcs; a.h0 = h0; a.S0 = S0;
     a.XS = XS; a.Hs = Hs; a.HP = HP; a.gates = gates; a.S = S; a.CS = CS;
     a.drop = L > 1 ? drop : nullptr; a.HD = Hdrop;
+#ifdef PPK_WS_TIMING
+    a.dbg = g_ws_dbg;
+#endif
     for (int t = 0; t < (int)T; ++t) a.bs[t] = (int)bs[t];
     // the same carve as the row-block persistent kernel with one group (seq_fwd_persist_ws_bytes covers it)
     const int nwg = (int)(H / 16);
@@ -924,6 +1110,9 @@ int seq_bwd_ws(int64_t T, const int64_t* bs, int64_t B, int64_t NT, int64_t H, i
     a.HP = HP; a.gates = gates; a.S = S; a.CS = CS; a.dHtop = dHtop;
     a.drop = L > 1 ? drop : nullptr;
     a.dXS = dXS; a.DGI = DGI; a.DGH = DGH; a.DCS = DCS; a.dh0 = dh0;
+#ifdef PPK_WS_TIMING
+    a.dbg = g_ws_dbg ? g_ws_dbg + 16 * 64 : nullptr;
+#endif
     for (int t = 0; t < (int)T; ++t) a.bs[t] = (int)bs[t];
     // the carve of the row-block persistent backward with one group (its first block, the k-major copy of the stack
     // columns of W_ih0, is not needed here: the registers are loaded from w_ih_t[0] directly)
@@ -947,3 +1136,8 @@ int seq_bwd_ws(int64_t T, const int64_t* bs, int64_t B, int64_t NT, int64_t H, i
 }
 
 }  // namespace ppk
+
+#ifdef PPK_WS_TIMING
+// diagnosis builds only (tools/ws_timing.py): [2 passes][64 workgroups][16] int64 cycle sums per phase (forward, then backward)
+extern "C" void ppk_dbg_ws_timing_buffer(long long* p) { g_ws_dbg = p; }
+#endif

@@ -5,7 +5,7 @@ set -e
 cd "$(dirname "$0")/../paccmann_polymer_amd/csrc"
 make -s -j8
 mkdir -p /tmp/ppk_alt
-for f in ppk_seq_persist ppk_seq_persist_bwd; do
+for f in ppk_seq_persist ppk_seq_persist_bwd ppk_seq_ws; do
   /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -fno-gpu-rdc -Wno-unused-function "$@" -c $f.hip -o /tmp/ppk_alt/$f.o
 done
 objs=""

@@ -117,22 +117,30 @@ __device__ __forceinline__ bool ws_wait(int* ctr, int target, int* status, volat
     return ok;
 }
 
-// this lane's KK consecutive floats of an activation row (handed-off data: L1-bypassing loads)
+// K index (inside a wave's chunk of 4 KK values) that MFMA m contracts in k-group g.  With 16-byte loads (KK % 4 == 0)
+// the four k-groups of a batch row read ADJACENT 16-byte pieces in one load instruction — 64 contiguous bytes per row and
+// instruction (16 line requests per wave instruction instead of 32, each line asked for once per two instructions instead
+// of four times): k = 16 x + 4 g + c for m = 4 x + c.  The weight registers use the same map.
+template <int KK> __device__ __forceinline__ constexpr int wk(int g, int m)
+{
+    return KK % 4 == 0 ? 16 * (m >> 2) + 4 * g + (m & 3) : g * KK + m;
+}
+// this lane's KK floats of an activation row (handed-off data: L1-bypassing loads); byte_off = the wave's chunk of the row
 template <int KK>
-__device__ __forceinline__ void load_b(float (&b)[KK], const float* base, long long byte_off)
+__device__ __forceinline__ void load_b(float (&b)[KK], const float* base, long long byte_off, int g)
 {
     if constexpr (KK % 4 == 0) {
 #pragma unroll
         for (int x = 0; x < KK / 4; ++x) {
-            const f32x4 v = ld4_sc1(base, byte_off + 16 * x);
+            const f32x4 v = ld4_sc1(base, byte_off + 64 * x + 16 * g);
             b[4 * x] = v[0]; b[4 * x + 1] = v[1]; b[4 * x + 2] = v[2]; b[4 * x + 3] = v[3];
         }
     } else if constexpr (KK == 2) {
-        const f32x2 v = ld2_sc1(base, byte_off);
+        const f32x2 v = ld2_sc1(base, byte_off + 8 * g);
         b[0] = v[0]; b[1] = v[1];
     } else {
         static_assert(KK == 1, "K / 32 is 1, 2 or a multiple of 4");
-        b[0] = ld1_sc1(base, byte_off);
+        b[0] = ld1_sc1(base, byte_off + 4 * g);
     }
 }
 
@@ -147,11 +155,11 @@ __device__ __forceinline__ void ws_product(f32x4 (&acc)[NR][4], const float (&w)
     float b0[KK], b1[KK];
     {
         const int r = n < bt ? n : bt - 1;
-        load_b<KK>(b0, X, ((row0 + r) * K + wave * 4 * KK + g * KK) * 4);
+        load_b<KK>(b0, X, ((row0 + r) * K + wave * 4 * KK) * 4, g);
     }
     if (NR > 1 && nrt > 1) {
         const int r = 16 + n < bt ? 16 + n : bt - 1;
-        load_b<KK>(b1, X, ((row0 + r) * K + wave * 4 * KK + g * KK) * 4);
+        load_b<KK>(b1, X, ((row0 + r) * K + wave * 4 * KK) * 4, g);
     }
 #pragma unroll
     for (int m = 0; m < KK; ++m) {
@@ -181,13 +189,13 @@ __device__ __forceinline__ void mma_gates(f32x4 (&acc)[4], const float (&w)[3][K
     }
 }
 
-// this lane's KK consecutive weights of gate row `grow` (a [rows x K] row-major matrix), K chunk of `wave`
+// this lane's KK weights (K map: wk) of gate row `grow` (a [rows x K] row-major matrix), K chunk of `wave`
 template <int KK>
 __device__ __forceinline__ void load_w(float (&w)[KK], const float* Wm, long long grow, int wave, int lane)
 {
-    const float* p = Wm + grow * (32 * KK) + wave * 4 * KK + (lane >> 4) * KK;
+    const float* p = Wm + grow * (32 * KK) + wave * 4 * KK;
 #pragma unroll
-    for (int m = 0; m < KK; ++m) w[m] = p[m];
+    for (int m = 0; m < KK; ++m) w[m] = p[wk<KK>(lane >> 4, m)];
 }
 
 // ---- stack update of the rows this workgroup owns (rho = j + k nwg), for the stack ENTERING step t ----------------------
@@ -272,7 +280,8 @@ __device__ __forceinline__ void ws_stack_rest(const WsArgs& a, int t, int j, int
 //   hpart[j][row][o] = sum_c h[row][16 j + c] wcs_t[16 j + c][o]        wave = (row tile, 16-column block of the outputs)
 __device__ __forceinline__ void ws_heads_partial(const WsArgs& a, const float (&wc)[4], const float* hown, int j, int bt, int wave, int lane)
 {
-    const int n = lane & 15, g = lane >> 4, ot = wave & 3, rt = wave >> 2;
+    // row tile 0 on waves 4 - 7: waves 0 and 1 are still issuing the cell's write-through stores
+    const int n = lane & 15, g = lane >> 4, ot = wave & 3, rt = (wave >> 2) ^ 1;
     if (16 * ot < a.ldcs && 16 * rt < bt) {
         const f32x4 hv = ld4(hown + (16 * rt + n) * 16 + 4 * g);
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -417,9 +426,9 @@ __global__ __launch_bounds__(NTH) void k_seq_fwd_ws(const WsArgs a)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) acc[0][q] = f32x4{0.f, 0.f, 0.f, 0.f};
             };
-            const long long lo = (wave * 4 * KH + g * KH) * 4;             // this lane's piece of a K = H row, bytes
+            const long long lo = (wave * 4 * KH) * 4;                       // this wave's chunk of a K = H row, bytes
             zero1();
-            load_b<KH>(b, a.h0, ((long long)(n < a.B ? n : a.B - 1) * H) * 4 + lo);
+            load_b<KH>(b, a.h0, ((long long)(n < a.B ? n : a.B - 1) * H) * 4 + lo, g);
             mma_gates<KH, 3>(acc[0], wh[0], b);
             for (int t = 0; t < a.T; ++t) {
                 const int bt = a.bs[t];
@@ -436,9 +445,9 @@ __global__ __launch_bounds__(NTH) void k_seq_fwd_ws(const WsArgs a)
                 prefetch(0, t, bt);
                 if (!ws_wait(ctr + 2 * CTR_STRIDE, NWG * (t + 1), a.status, &w_flag)) return;
                 WSTAMP(4);
-                load_b<KX>(bx, a.XS, ((base + rx) * KS + wave * 4 * KX + g * KX) * 4);
-                if (t > 0) load_b<KH>(bh, a.Hs + a.NT * H, (pbase + rx) * H * 4 + lo);
-                else load_b<KH>(bh, a.h0 + (long long)a.B * H, (long long)rx * H * 4 + lo);
+                load_b<KX>(bx, a.XS, ((base + rx) * KS + wave * 4 * KX) * 4, g);
+                if (t > 0) load_b<KH>(bh, a.Hs + a.NT * H, (pbase + rx) * H * 4 + lo, g);
+                else load_b<KH>(bh, a.h0 + (long long)a.B * H, (long long)rx * H * 4 + lo, g);
                 mma_gates<KX, 2>(acc[0], wi0, bx);
                 WSTAMP(5);
                 epilogue(acc, 0, t, bt, 1);
@@ -452,7 +461,7 @@ __global__ __launch_bounds__(NTH) void k_seq_fwd_ws(const WsArgs a)
                 WSTAMP(8);
                 if (!ws_wait(ctr, NWG * (t + 1), a.status, &w_flag)) return;
                 WSTAMP(9);
-                load_b<KH>(b, a.Hs, (base + rx) * H * 4 + lo);
+                load_b<KH>(b, a.Hs, (base + rx) * H * 4 + lo, g);
                 mma_gates<KH, 2>(acc[0], wi[0], b);
                 WSTAMP(10);
                 epilogue(acc, 1, t, bt, 1);
@@ -719,15 +728,15 @@ __global__ __launch_bounds__(NTH) void k_seq_bwd_ws(const WsBwdArgs a)
         for (int q = 0; q < 3; ++q) {
 #pragma unroll
             for (int l = 0; l < L; ++l) {
-                const float* p = a.w_hh_t[l] + urow * H3 + q * H + wave * 4 * KH + g * KH;
+                const float* p = a.w_hh_t[l] + urow * H3 + q * H + wave * 4 * KH;
 #pragma unroll
-                for (int m = 0; m < KH; ++m) whT[l][q][m] = p[m];
+                for (int m = 0; m < KH; ++m) whT[l][q][m] = p[wk<KH>(g, m)];
             }
 #pragma unroll
             for (int l = 1; l < L; ++l) {
-                const float* p = a.w_ih_t[l] + urow * H3 + q * H + wave * 4 * KH + g * KH;
+                const float* p = a.w_ih_t[l] + urow * H3 + q * H + wave * 4 * KH;
 #pragma unroll
-                for (int m = 0; m < KH; ++m) wiT[l - 1][q][m] = p[m];
+                for (int m = 0; m < KH; ++m) wiT[l - 1][q][m] = p[wk<KH>(g, m)];
             }
             // dXS partial: A[w][k], k = this workgroup's unit 4 g + mm of gate q; wave = (16-column block of w, row tile)
             const int wcol = 16 * (wave & 3) + n;
@@ -869,13 +878,13 @@ __global__ __launch_bounds__(NTH) void k_seq_bwd_ws(const WsBwdArgs a)
                 for (int rt = 0; rt < NR; ++rt)
                     if (rt < nrt) {
                         const int r = 16 * rt + n < bt ? 16 * rt + n : bt - 1;
-                        const long long bo = ((base + r) * H3 + wave * 4 * KH + g * KH) * 4;
+                        const long long bo = ((base + r) * H3 + wave * 4 * KH) * 4;
                         // every load of the row tile goes out before its first MFMA: one memory round trip, not four
                         float b0[KH], b1[KH], b2[KH], b3[KH];
-                        load_b<KH>(b0, gi, bo);                          // dr
-                        load_b<KH>(b1, gi, bo + 4LL * H);                // dz          (dgi == dgh for both)
-                        load_b<KH>(b2, gi, bo + 8LL * H);                // dn with W_ih
-                        load_b<KH>(b3, gh, bo + 8LL * H);                // dn r with W_hh
+                        load_b<KH>(b0, gi, bo, g);                          // dr
+                        load_b<KH>(b1, gi, bo + 4LL * H, g);                // dz          (dgi == dgh for both)
+                        load_b<KH>(b2, gi, bo + 8LL * H, g);                // dn with W_ih
+                        load_b<KH>(b3, gh, bo + 8LL * H, g);                // dn r with W_hh
                         mma_acc<KH>(accD[rt], wiT[l - 1][0], b0);
                         mma_acc<KH>(accC[rt], whT[l][0], b0);
                         mma_acc<KH>(accD[rt], wiT[l - 1][1], b1);
@@ -918,11 +927,11 @@ __global__ __launch_bounds__(NTH) void k_seq_bwd_ws(const WsBwdArgs a)
             for (int rt = 0; rt < NR; ++rt)
                 if (rt < nrt) {
                     const int r = 16 * rt + n < bt ? 16 * rt + n : bt - 1;
-                    const long long bo = ((base + r) * H3 + wave * 4 * KH + g * KH) * 4;
+                    const long long bo = ((base + r) * H3 + wave * 4 * KH) * 4;
                     float b0[KH], b1[KH], b2[KH];
-                    load_b<KH>(b0, a.DGH, bo);
-                    load_b<KH>(b1, a.DGH, bo + 4LL * H);
-                    load_b<KH>(b2, a.DGH, bo + 8LL * H);
+                    load_b<KH>(b0, a.DGH, bo, g);
+                    load_b<KH>(b1, a.DGH, bo + 4LL * H, g);
+                    load_b<KH>(b2, a.DGH, bo + 8LL * H, g);
                     mma_acc<KH>(accC[rt], whT[0][0], b0);
                     mma_acc<KH>(accC[rt], whT[0][1], b1);
                     mma_acc<KH>(accC[rt], whT[0][2], b2);

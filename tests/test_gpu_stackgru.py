@@ -57,6 +57,8 @@ def build_pair(params, seed, dtype):
 @pytest.mark.parametrize('params,B,lo,hi,seed', [
     (SMALL, 5, 3, 9, 0), (SMALL, 1, 4, 4, 1), (ODD, 7, 3, 12, 2), (SMALL, 9, 5, 5, 3), (FULL, 16, 5, 30, 4),
     (ONE, 6, 3, 8, 7), (ONE, 140, 2, 6, 8),          # one layer: the recurrent product of the only cell rides with the stack heads
+    (FULL, 21, 4, 24, 9), (FULL, 32, 3, 12, 10), (FULL, 17, 2, 9, 11), (FULL, 1, 6, 6, 12),      # the reference's bundle sizes: one and two 16-row tiles of the
+                                                                                              # weights-stationary kernels (ppk_seq_ws.hip), a second tile that empties early, a single row
 ])
 def test_train_step_matches_oracle_fp64(params, B, lo, hi, seed):
     check_train_step(params, B, lo, hi, seed)

@@ -174,7 +174,7 @@ int64_t ppk_nt_small_grid_limit(int64_t limit);
  * Weights-stationary shapes: B <= 32, L <= 2, H in {32, 64, 128, 256, 512} with ks == ldcs-minimal paddings, ldcs <= 64
  * (H >= 256: ks == 64 only), the owned rows' stacks within the workgroup's LDS (32 / (H / 16) rows x D x W floats: 2 images
  * forward, 3 backward), at least H / 16 CUs.  fp32 operands whatever ppk_mfma_mode says.  Measured (MI355X, H 512, L 2,
- * bundles of 6 - 21 sequences of 20 - 100 tokens, whole training step): 15.8 ms -> 8.7 ms (profiles/r03_small_batch_ws.txt).
+ * bundles of 6 - 21 sequences of 20 - 100 tokens, whole training step): 15.7 ms -> 8.3 ms (profiles/r03_small_batch_ws.txt).
  * Any other value only queries.  Process-global like ppk_nt_small_grid_limit.  Returns the value in force.
  * A persistent launch (either kind) whose workgroups lose a hand-off (bounded wait, ~3 s; another process holding the GPU can cause
  * it) fills every output of the call with NaN: the entry point still returns PPK_OK (it never synchronises). */

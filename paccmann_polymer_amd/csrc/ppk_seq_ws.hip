@@ -790,6 +790,39 @@ __global__ __launch_bounds__(NTH) void k_seq_bwd_ws(const WsBwdArgs a)
         __syncthreads();
     };
 
+    // carry_0 += dgh_0 . W_hh[0] is needed one step later only, and its 96 KB of operand rows are more than one hand-off
+    // window hides: with two or more layers the r and z thirds are contracted behind the DCS signal of the step (accK
+    // stays in registers), the n third behind the first signal of the NEXT step, where the partial tiles are summed
+    f32x4 accK[NR];
+#pragma unroll
+    for (int rt = 0; rt < NR; ++rt) accK[rt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    bool have_k = false;
+    auto carry0_part = [&](int q0, int q1, int rows, long long rowbase, int ntile) {
+#pragma unroll
+        for (int rt = 0; rt < NR; ++rt)
+            if (rt < ntile) {
+                const int r = 16 * rt + n < rows ? 16 * rt + n : rows - 1;
+                const long long bo = ((rowbase + r) * H3 + wave * 4 * KH) * 4;
+                float b0[KH], b1[KH], b2[KH];
+                if (q0 <= 0 && 0 < q1) load_b<KH>(b0, a.DGH, bo, g);
+                if (q0 <= 1 && 1 < q1) load_b<KH>(b1, a.DGH, bo + 4LL * H, g);
+                if (q0 <= 2 && 2 < q1) load_b<KH>(b2, a.DGH, bo + 8LL * H, g);
+                if (q0 <= 0 && 0 < q1) mma_acc<KH>(accK[rt], whT[0][0], b0);
+                if (q0 <= 1 && 1 < q1) mma_acc<KH>(accK[rt], whT[0][1], b1);
+                if (q0 <= 2 && 2 < q1) mma_acc<KH>(accK[rt], whT[0][2], b2);
+            }
+    };
+    auto carry0_finish = [&](int rows, int ntile) {
+        reduce(accK, accK, 1, ntile, rows);
+        if (tid < 4 * WROWS && (tid >> 2) < rows) {
+            float* cp = w_carry + (tid >> 2) * 16 + 4 * (tid & 3);
+            st4(cp, ld4(cp) + ld4(w_red + (tid >> 2) * 16 + 4 * (tid & 3)));
+        }
+        __syncthreads();
+#pragma unroll
+        for (int rt = 0; rt < NR; ++rt) accK[rt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    };
+
     for (int t = a.T - 1, kstep = 0; t >= 0; --t, ++kstep) {
         const int bt = a.bs[t], nn = t + 1 < a.T ? a.bs[t + 1] : 0, nrt = (bt + 15) >> 4, nrtn = (nn + 15) >> 4;
         const long long base = w_off[t], nbase = w_off[t + 1];
@@ -867,6 +900,11 @@ __global__ __launch_bounds__(NTH) void k_seq_bwd_ws(const WsBwdArgs a)
             WSTAMP(4);
             // ---- P_l: accD = dgi_l . W_ih[l] (-> dh_{l-1}), accC = dgh_l . W_hh[l] (-> carry_l)
             prefetch(l - 1, t, bt);
+            if (l == L - 1 && have_k) {                    // inside the hand-off window: the rest of the previous step's carry_0
+                carry0_part(2, 3, nn, nbase, nrtn);
+                carry0_finish(nn, nrtn);
+                have_k = false;
+            }
             zero(accD);
             zero(accC);
             if (!ws_wait(ctr + l * CTR_STRIDE, NWG * (kstep + 1), a.status, &w_flag)) return;
@@ -921,32 +959,21 @@ __global__ __launch_bounds__(NTH) void k_seq_bwd_ws(const WsBwdArgs a)
         // ---- carry_0 += dgh_0 . W_hh[0]: only this workgroup's next step needs it — it fills the DCS hand-off.  (Requesting
         // its 96 KB of rows before the owners finish their stack rows put those loads in front of the owners' dXS partials:
         // 44.4 -> 48.6 k cycles per timestep, not kept.)
-        {
-            zero(accC);
-#pragma unroll
-            for (int rt = 0; rt < NR; ++rt)
-                if (rt < nrt) {
-                    const int r = 16 * rt + n < bt ? 16 * rt + n : bt - 1;
-                    const long long bo = ((base + r) * H3 + wave * 4 * KH) * 4;
-                    float b0[KH], b1[KH], b2[KH];
-                    load_b<KH>(b0, a.DGH, bo, g);
-                    load_b<KH>(b1, a.DGH, bo + 4LL * H, g);
-                    load_b<KH>(b2, a.DGH, bo + 8LL * H, g);
-                    mma_acc<KH>(accC[rt], whT[0][0], b0);
-                    mma_acc<KH>(accC[rt], whT[0][1], b1);
-                    mma_acc<KH>(accC[rt], whT[0][2], b2);
-                }
-            reduce(accC, accC, 1, nrt, bt);
-            if (tid < 4 * WROWS && (tid >> 2) < bt) {
-                float* cp = w_carry + (tid >> 2) * 16 + 4 * (tid & 3);
-                st4(cp, ld4(cp) + ld4(w_red + (tid >> 2) * 16 + 4 * (tid & 3)));
-            }
-            __syncthreads();
+        if constexpr (L > 1) {
+            carry0_part(0, 2, bt, base, nrt);
+            have_k = true;
+        } else {
+            carry0_part(0, 3, bt, base, nrt);
+            carry0_finish(bt, nrt);
         }
         WSTAMP(10);
     }
     // the stack of step 0 read the INITIAL hidden state of the top layer: dh0[L-1] += DCS_0 . [W_c ; W_s]
     {
+        if (have_k) {
+            carry0_part(2, 3, a.B, 0, (a.B + 15) >> 4);
+            carry0_finish(a.B, (a.B + 15) >> 4);
+        }
         if (!ws_wait(ctr + L * CTR_STRIDE, NWG * a.T, a.status, &w_flag)) return;
         f32x4 accD[NR];
         const int kc = a.ldcs >> 5, nrt = (a.B + 15) >> 4;

@@ -68,6 +68,8 @@ int seq_fwd_persist(int64_t T, const int64_t* bs, int64_t B, int64_t NT, int64_t
 
 // ---- small-batch (<= 32 rows) weights-stationary forward (ppk_seq_ws.hip): H / 16 workgroups keep their gate rows of
 //      every matrix in registers for the whole launch; same arguments, outputs and workspace as seq_fwd_persist ----
+size_t seq_fwd_ws_ws_bytes(int64_t B, int64_t H, int64_t L, int64_t W);      // 0 where these kernels do not apply
+size_t seq_bwd_ws_ws_bytes(int64_t B, int64_t H, int64_t L, int64_t W);
 bool seq_fwd_ws_ok(int64_t T, int64_t B, int64_t NT, int64_t H, int64_t L, int64_t W, int64_t D, int64_t ks, int64_t ldcs);
 int seq_fwd_ws(int64_t T, const int64_t* bs, int64_t B, int64_t NT, int64_t V, int64_t H, int64_t L, int64_t W, int64_t D,
                const int64_t* tokens, const float* table, const float* wx0s, int64_t ks,

@@ -25,6 +25,7 @@
 #include "ppk_common.h"
 #include "ppk_kernels.h"
 #include "ppk_seq_common.h"
+#include <stdlib.h>
 #include <algorithm>
 
 namespace {
@@ -40,7 +41,7 @@ constexpr int WS_MAXL = 2;
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 struct WsArgs {
-    int T, B, W, D, V, ldcs, DW;
+    int T, B, W, D, V, ldcs, DW, R;
     long long NT;
     const int64_t* tokens;
     const float* table; const float* wx0s;
@@ -48,7 +49,7 @@ struct WsArgs {
     const float* wcs_t; const float* bcs; const float* h0; const float* S0;
     float* XS; float* Hs; float* HP; float* gates; float* S; float* CS;
     const float* drop; float* HD;
-    float* hpart;                              // [nwg][32][ldcs]: head partials, rewritten every step
+    float* hpart;                              // [R][nwg][32][ldcs]: head partials, rewritten every step
     int* ctr; int* status;
     long long* dbg;
     int bs[MAXT];
@@ -77,6 +78,13 @@ long long* g_ws_dbg = nullptr;
 #define WSTAMP_DUMP(dbg, j) do { } while (0)
 #endif
 
+// Replicas: a batch of more than 16 (32) sequences is dealt round-robin (in length order: every replica gets the same
+// length profile) to R independent replicas of H / 16 workgroups; replica `rep` owns the sorted rows rep, rep + R, ...
+// Each has its own counters and partial buffers and never talks to another; all hold the same weights.
+struct Rep { int rep, R; };
+__device__ __forceinline__ int rows_of(int bs_t, Rep r) { const int v = bs_t - r.rep; return v <= 0 ? 0 : (v + r.R - 1) / r.R; }      // active local rows
+__device__ __forceinline__ long long prow(long long base, int row, Rep r) { return base + r.rep + (long long)r.R * row; }             // packed row of a local row
+
 __device__ __forceinline__ f32x2 ld2_sc1(const float* base, long long byte_off)
 {
     return __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(make_rsrc(base), (int)byte_off, 0, CPOL_SC1));
@@ -99,7 +107,8 @@ __device__ __forceinline__ bool ws_wait(int* ctr, int target, int* status, volat
 {
     if (threadIdx.x == 0) {
         int ok = 0;
-        for (int it = 0; it < SPIN_LIMIT * (32 / PPK_WS_POLL_SLEEP); ++it) {
+        constexpr int POLLS = SPIN_LIMIT == 1 ? 1 : SPIN_LIMIT * (32 / PPK_WS_POLL_SLEEP);      // ~3 s; the give-up-at-once test build polls once
+        for (int it = 0; it < POLLS; ++it) {
             if (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target) { ok = 1; break; }
             if ((it & 1023) == 1023 && __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
             __builtin_amdgcn_s_sleep(PPK_WS_POLL_SLEEP);
@@ -148,18 +157,18 @@ __device__ __forceinline__ void load_b(float (&b)[KK], const float* base, long l
 // lane (n = lane & 15, g = lane >> 4) holds k = chunk + g KK + m of unit n (weights) and of batch row 16 rt + n (X)
 template <int KK, int NSEL, int NR>
 __device__ __forceinline__ void ws_product(f32x4 (&acc)[NR][4], const float (&w)[3][KK], const float* X, long long row0, int bt, int nrt,
-                                           int wave, int lane)
+                                           int wave, int lane, Rep rp)
 {
     const int n = lane & 15, g = lane >> 4;
     constexpr int K = 32 * KK;
     float b0[KK], b1[KK];
     {
         const int r = n < bt ? n : bt - 1;
-        load_b<KK>(b0, X, ((row0 + r) * K + wave * 4 * KK) * 4, g);
+        load_b<KK>(b0, X, (prow(row0, r, rp) * K + wave * 4 * KK) * 4, g);
     }
     if (NR > 1 && nrt > 1) {
         const int r = 16 + n < bt ? 16 + n : bt - 1;
-        load_b<KK>(b1, X, ((row0 + r) * K + wave * 4 * KK) * 4, g);
+        load_b<KK>(b1, X, (prow(row0, r, rp) * K + wave * 4 * KK) * 4, g);
     }
 #pragma unroll
     for (int m = 0; m < KK; ++m) {
@@ -203,17 +212,18 @@ __device__ __forceinline__ void load_w(float (&w)[KK], const float* Wm, long lon
 // softmax(3) / tanh(W), then ONLY the new stack top (W elements) -> XS, handed to the group.  ws_stack_rest, behind the
 // signal: the push / pop / no-op blend of the whole row's image in LDS into its other image, the new row to S and the
 // activations to CS (both read by later kernels only) — off the group's critical path.
-__device__ __forceinline__ void ws_stack_top(const WsArgs& a, int t, int j, int nwg, int ks)
+__device__ __forceinline__ void ws_stack_top(const WsArgs& a, int t, int j, int nwg, int ks, Rep rp)
 {
-    const int tid = threadIdx.x, bt = a.bs[t], ldcs = a.ldcs, W = a.W, DW = a.DW, DW4 = (DW + 3) & ~3, nout = 3 + W;
+    const int tid = threadIdx.x, bt = rows_of(a.bs[t], rp), ldcs = a.ldcs, W = a.W, DW = a.DW, DW4 = (DW + 3) & ~3, nout = 3 + W;
     const long long base = w_off[t];
     float* hp = w_part;                                // [nwg][ldcs]
+    const float* hpart = a.hpart + (long long)rp.rep * nwg * WROWS * ldcs;
     for (int k = 0; j + k * nwg < bt; ++k) {           // workgroup-uniform
         const int rho = j + k * nwg;
         float* act = w_act + 64 * k;
         for (int e = tid; e < nwg * (ldcs >> 2); e += NTH) {
             const int jj = e / (ldcs >> 2), o = (e - jj * (ldcs >> 2)) * 4;
-            st4(hp + jj * ldcs + o, ld4_sc1(a.hpart, (((long long)jj * WROWS + rho) * ldcs + o) * 4));
+            st4(hp + jj * ldcs + o, ld4_sc1(hpart, (((long long)jj * WROWS + rho) * ldcs + o) * 4));
         }
         __syncthreads();
         if (tid < ldcs) {
@@ -237,12 +247,12 @@ __device__ __forceinline__ void ws_stack_top(const WsArgs& a, int t, int j, int 
             w_top[tid] = v;
         }
         __syncthreads();
-        if (tid < (ks >> 2)) st4_sc1(a.XS, ((base + rho) * ks + 4 * tid) * 4, ld4(w_top + 4 * tid));      // handed to the group
+        if (tid < (ks >> 2)) st4_sc1(a.XS, (prow(base, rho, rp) * ks + 4 * tid) * 4, ld4(w_top + 4 * tid));      // handed to the group
     }
 }
-__device__ __forceinline__ void ws_stack_rest(const WsArgs& a, int t, int j, int nwg)
+__device__ __forceinline__ void ws_stack_rest(const WsArgs& a, int t, int j, int nwg, Rep rp)
 {
-    const int tid = threadIdx.x, bt = a.bs[t], ldcs = a.ldcs, W = a.W, DW = a.DW, DW4 = (DW + 3) & ~3, nout = 3 + W;
+    const int tid = threadIdx.x, bt = rows_of(a.bs[t], rp), ldcs = a.ldcs, W = a.W, DW = a.DW, DW4 = (DW + 3) & ~3, nout = 3 + W;
     const long long base = w_off[t];
     const bool vec = (DW & 3) == 0;
     for (int k = 0; j + k * nwg < bt; ++k) {           // workgroup-uniform
@@ -251,7 +261,7 @@ __device__ __forceinline__ void ws_stack_rest(const WsArgs& a, int t, int j, int
         const float a_push = act[0], a_pop = act[1], a_noop = act[2];
         const float* sp = w_stack + (2 * k + ((t & 1) ^ 1)) * DW4;
         float* sn = w_stack + (2 * k + (t & 1)) * DW4;
-        float* sg = a.S + (base + rho) * DW;
+        float* sg = a.S + prow(base, rho, rp) * DW;
         auto upd = [&](int e) {
             const float up = e < W ? act[3 + e] : sp[e - W];
             const float down = e + W < DW ? sp[e + W] : 0.f;
@@ -272,13 +282,13 @@ __device__ __forceinline__ void ws_stack_rest(const WsArgs& a, int t, int j, int
                 sg[e] = v;
             }
         }
-        if (tid < nout) a.CS[(base + rho) * ldcs + tid] = act[tid];
+        if (tid < nout) a.CS[prow(base, rho, rp) * ldcs + tid] = act[tid];
     }
 }
 
 // ---- heads partial of this workgroup's 16 units of the top layer's hidden state (w_hown) ---------------------------
 //   hpart[j][row][o] = sum_c h[row][16 j + c] wcs_t[16 j + c][o]        wave = (row tile, 16-column block of the outputs)
-__device__ __forceinline__ void ws_heads_partial(const WsArgs& a, const float (&wc)[4], const float* hown, int j, int bt, int wave, int lane)
+__device__ __forceinline__ void ws_heads_partial(const WsArgs& a, const float* hpart, const float (&wc)[4], const float* hown, int j, int bt, int wave, int lane)
 {
     // row tile 0 on waves 4 - 7: waves 0 and 1 are still issuing the cell's write-through stores
     const int n = lane & 15, g = lane >> 4, ot = wave & 3, rt = (wave >> 2) ^ 1;
@@ -287,7 +297,7 @@ __device__ __forceinline__ void ws_heads_partial(const WsArgs& a, const float (&
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int m = 0; m < 4; ++m) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wc[m], hv[m], acc, 0, 0, 0);
-        if (16 * rt + n < bt) st4_sc1(a.hpart, (((long long)j * WROWS + 16 * rt + n) * a.ldcs + 16 * ot + 4 * g) * 4, acc);
+        if (16 * rt + n < bt) st4_sc1(hpart, (((long long)j * WROWS + 16 * rt + n) * a.ldcs + 16 * ot + 4 * g) * 4, acc);
     }
 }
 
@@ -295,7 +305,10 @@ template <int H, int KS, int L, int NR>
 __global__ __launch_bounds__(NTH) void k_seq_fwd_ws(const WsArgs a)
 {
     constexpr int KH = H / 32, KX = KS / 32, NWG = H / 16;
-    const int j = blockIdx.x;
+    const int rep = blockIdx.x / NWG, j = blockIdx.x - rep * NWG;
+    const Rep rp{rep, a.R};
+    const int Bl = rows_of(a.B, rp);                    // rows of this replica
+    const float* hpart = a.hpart + (long long)rep * NWG * WROWS * a.ldcs;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n = lane & 15, g = lane >> 4;
     const long long H3 = 3LL * H;
@@ -321,21 +334,21 @@ __global__ __launch_bounds__(NTH) void k_seq_fwd_ws(const WsArgs a)
     for (int e = tid; e < L * WROWS * 4; e += NTH) {
         const int l = e / (WROWS * 4), row = (e >> 2) & (WROWS - 1), u4 = e & 3;
         st4(w_hown + (l * WROWS + row) * 16 + 4 * u4,
-            row < a.B ? ld4(a.h0 + ((long long)l * a.B + row) * H + 16 * j + 4 * u4) : f32x4{0.f, 0.f, 0.f, 0.f});
+            row < Bl ? ld4(a.h0 + ((long long)l * a.B + prow(0, row, rp)) * H + 16 * j + 4 * u4) : f32x4{0.f, 0.f, 0.f, 0.f});
     }
     {
         const int DW4 = (a.DW + 3) & ~3;
-        for (int k = 0; j + k * NWG < a.B; ++k) {
+        for (int k = 0; j + k * NWG < Bl; ++k) {
             float* img = w_stack + (2 * k + 1) * DW4;                 // the image step 0 reads
-            for (int e = tid; e < a.DW; e += NTH) img[e] = a.S0 ? a.S0[(long long)(j + k * NWG) * a.DW + e] : 0.f;
+            for (int e = tid; e < a.DW; e += NTH) img[e] = a.S0 ? a.S0[prow(0, j + k * NWG, rp) * a.DW + e] : 0.f;
         }
     }
     if (tid < 64) w_top[tid] = 0.f;
     __syncthreads();
     WSTAMP_INIT();
-    int* ctr = a.ctr;
+    int* ctr = a.ctr + (long long)rep * (L + 1) * CTR_STRIDE;
     // "step -1": the heads of the initial hidden state of the top layer
-    ws_heads_partial(a, wc, w_hown + (L - 1) * WROWS * 16, j, a.B, wave, lane);
+    ws_heads_partial(a, hpart, wc, w_hown + (L - 1) * WROWS * 16, j, Bl, wave, lane);
     group_signal(ctr + (L - 1) * CTR_STRIDE);
 
     // epilogue of a layer: dump the K-chunk partials, sum them in wave order, GRU cell on the sums (one element per
@@ -377,19 +390,19 @@ __global__ __launch_bounds__(NTH) void k_seq_fwd_ws(const WsArgs a)
         }
         __syncthreads();
         if (tid < 4 * WROWS && (tid >> 2) < bt) {
-            const long long prow = (long long)l * a.NT + base + (tid >> 2);
+            const long long pr = (long long)l * a.NT + prow(base, tid >> 2, rp);
             const int u = 16 * j + 4 * (tid & 3);
             const f32x4 ho = ld4(w_hown + l * 512 + 4 * tid);
-            st4_sc1(a.Hs, (prow * H + u) * 4, ho);                                           // handed to the group
-            if (a.drop && l < L - 1) st4_sc1(a.HD, (prow * H + u) * 4, ho * ld4(a.drop + prow * H + u));
+            st4_sc1(a.Hs, (pr * H + u) * 4, ho);                                             // handed to the group
+            if (a.drop && l < L - 1) st4_sc1(a.HD, (pr * H + u) * 4, ho * ld4(a.drop + pr * H + u));
         }
     };
     auto epilogue_tail = [&](int l, int t, int bt) {
         if (tid < 4 * WROWS && (tid >> 2) < bt) {
-            const long long prow = (long long)l * a.NT + w_off[t] + (tid >> 2);
+            const long long pr = (long long)l * a.NT + prow(w_off[t], tid >> 2, rp);
             const int u = 16 * j + 4 * (tid & 3);
-            st4(a.HP + prow * H + u, ld4(cellv + 4 * tid));
-            float* gt = a.gates + prow * 4 * H + u;
+            st4(a.HP + pr * H + u, ld4(cellv + 4 * tid));
+            float* gt = a.gates + pr * 4 * H + u;
             st4(gt, ld4(cellv + 512 + 4 * tid)); st4(gt + H, ld4(cellv + 1024 + 4 * tid));
             st4(gt + 2 * H, ld4(cellv + 1536 + 4 * tid)); st4(gt + 3 * H, ld4(cellv + 2048 + 4 * tid));
         }
@@ -402,7 +415,7 @@ __global__ __launch_bounds__(NTH) void k_seq_fwd_ws(const WsArgs a)
             const int row = tid >> 2, u = 16 * j + 4 * (tid & 3);
             const float* tp;
             if (l == 0) {
-                const long long tok = a.tokens[w_off[t] + row];
+                const long long tok = a.tokens[prow(w_off[t], row, rp)];
                 tp = a.table + (tok < 0 ? 0 : (tok < a.V ? tok : a.V - 1)) * H3 + u;
             } else tp = a.b_ih[l] + u;
             const float* bp = a.b_hh[l] + u;
@@ -428,26 +441,27 @@ __global__ __launch_bounds__(NTH) void k_seq_fwd_ws(const WsArgs a)
             };
             const long long lo = (wave * 4 * KH) * 4;                       // this wave's chunk of a K = H row, bytes
             zero1();
-            load_b<KH>(b, a.h0, ((long long)(n < a.B ? n : a.B - 1) * H) * 4 + lo, g);
+            load_b<KH>(b, a.h0, prow(0, n < Bl ? n : Bl - 1, rp) * H * 4 + lo, g);
             mma_gates<KH, 3>(acc[0], wh[0], b);
             for (int t = 0; t < a.T; ++t) {
-                const int bt = a.bs[t];
+                const int bt = rows_of(a.bs[t], rp);
+                if (bt == 0) break;                                  // this replica's longest sequence has ended
                 const long long base = w_off[t], pbase = t > 0 ? w_off[t - 1] : 0;
                 const int rx = n < bt ? n : bt - 1;
                 WSTAMP(0);
                 if (!ws_wait(ctr + CTR_STRIDE, NWG * (t + 1), a.status, &w_flag)) return;
                 WSTAMP(1);
-                ws_stack_top(a, t, j, NWG, KS);
+                ws_stack_top(a, t, j, NWG, KS, rp);
                 WSTAMP(2);
                 group_signal(ctr + 2 * CTR_STRIDE);
                 WSTAMP(3);
-                ws_stack_rest(a, t, j, NWG);
+                ws_stack_rest(a, t, j, NWG, rp);
                 prefetch(0, t, bt);
                 if (!ws_wait(ctr + 2 * CTR_STRIDE, NWG * (t + 1), a.status, &w_flag)) return;
                 WSTAMP(4);
-                load_b<KX>(bx, a.XS, ((base + rx) * KS + wave * 4 * KX) * 4, g);
-                if (t > 0) load_b<KH>(bh, a.Hs + a.NT * H, (pbase + rx) * H * 4 + lo, g);
-                else load_b<KH>(bh, a.h0 + (long long)a.B * H, (long long)rx * H * 4 + lo, g);
+                load_b<KX>(bx, a.XS, (prow(base, rx, rp) * KS + wave * 4 * KX) * 4, g);
+                if (t > 0) load_b<KH>(bh, a.Hs + a.NT * H, prow(pbase, rx, rp) * H * 4 + lo, g);
+                else load_b<KH>(bh, a.h0 + (long long)a.B * H, prow(0, rx, rp) * H * 4 + lo, g);
                 mma_gates<KX, 2>(acc[0], wi0, bx);
                 WSTAMP(5);
                 epilogue(acc, 0, t, bt, 1);
@@ -461,12 +475,12 @@ __global__ __launch_bounds__(NTH) void k_seq_fwd_ws(const WsArgs a)
                 WSTAMP(8);
                 if (!ws_wait(ctr, NWG * (t + 1), a.status, &w_flag)) return;
                 WSTAMP(9);
-                load_b<KH>(b, a.Hs, (base + rx) * H * 4 + lo, g);
+                load_b<KH>(b, a.Hs, prow(base, rx, rp) * H * 4 + lo, g);
                 mma_gates<KH, 2>(acc[0], wi[0], b);
                 WSTAMP(10);
                 epilogue(acc, 1, t, bt, 1);
                 WSTAMP(11);
-                ws_heads_partial(a, wc, w_hown + WROWS * 16, j, bt, wave, lane);
+                ws_heads_partial(a, hpart, wc, w_hown + WROWS * 16, j, bt, wave, lane);
                 WSTAMP(12);
                 group_signal(ctr + CTR_STRIDE);
                 WSTAMP(13);
@@ -480,7 +494,8 @@ __global__ __launch_bounds__(NTH) void k_seq_fwd_ws(const WsArgs a)
     }
 
     for (int t = 0; t < a.T; ++t) {
-        const int bt = a.bs[t], nrt = (bt + 15) >> 4;
+        const int bt = rows_of(a.bs[t], rp), nrt = (bt + 15) >> 4;
+        if (bt == 0) break;                                          // this replica's longest sequence has ended
         const long long base = w_off[t], pbase = t > 0 ? w_off[t - 1] : 0;
         f32x4 acc[NR][4];
         auto zero = [&]() {
@@ -490,8 +505,8 @@ __global__ __launch_bounds__(NTH) void k_seq_fwd_ws(const WsArgs a)
                 for (int q = 0; q < 4; ++q) acc[rt][q] = f32x4{0.f, 0.f, 0.f, 0.f};
         };
         auto hidden_product = [&](int l) {             // W_hh[l] . h_l(t-1): every unit of it was handed off one phase ago
-            if (t > 0) ws_product<KH, 3, NR>(acc, wh[l], a.Hs + (long long)l * a.NT * H, pbase, bt, nrt, wave, lane);
-            else ws_product<KH, 3, NR>(acc, wh[l], a.h0 + (long long)l * a.B * H, 0, bt, nrt, wave, lane);
+            if (t > 0) ws_product<KH, 3, NR>(acc, wh[l], a.Hs + (long long)l * a.NT * H, pbase, bt, nrt, wave, lane, rp);
+            else ws_product<KH, 3, NR>(acc, wh[l], a.h0 + (long long)l * a.B * H, 0, bt, nrt, wave, lane, rp);
         };
         zero();
         if constexpr (L > 1) hidden_product(0);
@@ -499,20 +514,20 @@ __global__ __launch_bounds__(NTH) void k_seq_fwd_ws(const WsArgs a)
         // the stack entering this step: heads of the top layer's hidden state of the step before
         if (!ws_wait(ctr + (L - 1) * CTR_STRIDE, NWG * (t + 1), a.status, &w_flag)) return;
         WSTAMP(1);
-        ws_stack_top(a, t, j, NWG, KS);
+        ws_stack_top(a, t, j, NWG, KS, rp);
         WSTAMP(2);
         group_signal(ctr + L * CTR_STRIDE);
         WSTAMP(3);
-        ws_stack_rest(a, t, j, NWG);
+        ws_stack_rest(a, t, j, NWG, rp);
         if constexpr (L == 1) hidden_product(0);
         // layer 0: + W_ih0[:, E:] . stack top, + table[token]
         prefetch(0, t, bt);
         if (!ws_wait(ctr + L * CTR_STRIDE, NWG * (t + 1), a.status, &w_flag)) return;
         WSTAMP(4);
-        ws_product<KX, 2, NR>(acc, wi0, a.XS, base, bt, nrt, wave, lane);
+        ws_product<KX, 2, NR>(acc, wi0, a.XS, base, bt, nrt, wave, lane, rp);
         WSTAMP(5);
         epilogue(acc, 0, t, bt, nrt);
-        if constexpr (L == 1) ws_heads_partial(a, wc, w_hown, j, bt, wave, lane);
+        if constexpr (L == 1) ws_heads_partial(a, hpart, wc, w_hown, j, bt, wave, lane);
         WSTAMP(6);
         group_signal(ctr);
         WSTAMP(7);
@@ -525,11 +540,11 @@ __global__ __launch_bounds__(NTH) void k_seq_fwd_ws(const WsArgs a)
             WSTAMP(8);
             if (!ws_wait(ctr + (l - 1) * CTR_STRIDE, NWG * (t + 1), a.status, &w_flag)) return;
             WSTAMP(9);
-            ws_product<KH, 2, NR>(acc, wi[l - 1], (a.drop ? a.HD : a.Hs) + (long long)(l - 1) * a.NT * H, base, bt, nrt, wave, lane);
+            ws_product<KH, 2, NR>(acc, wi[l - 1], (a.drop ? a.HD : a.Hs) + (long long)(l - 1) * a.NT * H, base, bt, nrt, wave, lane, rp);
             WSTAMP(10);
             epilogue(acc, l, t, bt, nrt);
             WSTAMP(11);
-            if (l == L - 1) ws_heads_partial(a, wc, w_hown + l * WROWS * 16, j, bt, wave, lane);
+            if (l == L - 1) ws_heads_partial(a, hpart, wc, w_hown + l * WROWS * 16, j, bt, wave, lane);
             WSTAMP(12);
             group_signal(ctr + l * CTR_STRIDE);
             WSTAMP(13);
@@ -564,12 +579,12 @@ __global__ __launch_bounds__(256) void k_ws_wcs_transpose(const float* __restric
 // K order of the 3H contractions: [gate][unit], a wave takes units [w H/8, (w+1) H/8) of every gate, so the r and z
 // thirds (dgi == dgh) are loaded once.
 struct WsBwdArgs {
-    int T, B, W, D, ldcs, DW;
+    int T, B, W, D, ldcs, DW, R;
     long long NT;
     const float* w_ih_t[WS_MAXL]; const float* w_hh_t[WS_MAXL]; const float* wcs_t;
     const float* HP; const float* gates; const float* S; const float* CS; const float* dHtop; const float* drop;
     float* dXS; float* DGI; float* DGH; float* DCS; float* dh0;
-    float* xpart;                              // [nwg][32][ks]: dXS partials, rewritten every step
+    float* xpart;                              // [R][nwg][32][ks]: dXS partials, rewritten every step
     int* ctr; int* status;
     long long* dbg;
     int bs[MAXT];
@@ -595,17 +610,17 @@ __device__ __forceinline__ void mma_acc(f32x4& acc, const float (&w)[KK], const 
 // products over the elements i >= W and the outgoing gradient of the elements i >= 2W — is computed BEFORE the wait for
 // the group's dXS partials, next to the LDS-DMA requests for the previous stack rows; behind the wait only 2W elements
 // and the DCS row remain.
-__device__ __forceinline__ void ws_stack_bwd_pre(const WsBwdArgs& a, int t, int kstep, int j, int nwg)
+__device__ __forceinline__ void ws_stack_bwd_pre(const WsBwdArgs& a, int t, int kstep, int j, int nwg, Rep rp)
 {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int bt = a.bs[t], ldcs = a.ldcs, W = a.W, DW = a.DW, DW4 = (DW + 3) & ~3, nout = 3 + W, n4 = DW >> 2;
+    const int bt = rows_of(a.bs[t], rp), ldcs = a.ldcs, W = a.W, DW = a.DW, DW4 = (DW + 3) & ~3, nout = 3 + W, n4 = DW >> 2;
     const long long base = w_off[t], pbase = t > 0 ? w_off[t - 1] : 0;
     const bool vec = (DW & 3) == 0;
     const int par = kstep & 1;
     // previous stack rows of the owned rows (forward output: plain memory) and their saved activations
     for (int k = 0; j + k * nwg < bt; ++k) {
         float* spl = w_bstack + (3 * k + 2) * DW4;
-        const float* src = a.S + (pbase + j + k * nwg) * DW;
+        const float* src = a.S + prow(pbase, j + k * nwg, rp) * DW;
         if (t == 0) { for (int e = tid; e < DW; e += NTH) spl[e] = 0.f; }
         else if (vec) {
             for (int pi = wave; pi * 64 < n4; pi += 8) {
@@ -613,7 +628,7 @@ __device__ __forceinline__ void ws_stack_bwd_pre(const WsBwdArgs& a, int t, int 
                 if (e < n4) __builtin_amdgcn_global_load_lds(src + 4 * e, PPK_LDS_PTR(spl + pi * 256), 16, 0, 0);
             }
         } else { for (int e = tid; e < DW; e += NTH) spl[e] = src[e]; }
-        if (tid < ldcs) w_act[64 * k + tid] = tid < nout ? a.CS[(base + j + k * nwg) * ldcs + tid] : 0.f;
+        if (tid < ldcs) w_act[64 * k + tid] = tid < nout ? a.CS[prow(base, j + k * nwg, rp) * ldcs + tid] : 0.f;
     }
     wait_vmcnt<0>();
     __syncthreads();
@@ -641,13 +656,14 @@ __device__ __forceinline__ void ws_stack_bwd_pre(const WsBwdArgs& a, int t, int 
         if (lane == 0) { float* r = w_rsum + (k * 8 + wave) * 4; r[0] = s0; r[1] = s1; r[2] = s2; }
     }
 }
-__device__ __forceinline__ void ws_stack_bwd_post(const WsBwdArgs& a, int t, int kstep, int j, int nwg, int ks)
+__device__ __forceinline__ void ws_stack_bwd_post(const WsBwdArgs& a, int t, int kstep, int j, int nwg, int ks, Rep rp)
 {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int bt = a.bs[t], ldcs = a.ldcs, W = a.W, DW = a.DW, DW4 = (DW + 3) & ~3, nout = 3 + W;
+    const int bt = rows_of(a.bs[t], rp), ldcs = a.ldcs, W = a.W, DW = a.DW, DW4 = (DW + 3) & ~3, nout = 3 + W;
     const long long base = w_off[t];
     const int par = kstep & 1;
     float* xp = w_bpart;                                // [nwg][ks]
+    const float* xpart = a.xpart + (long long)rp.rep * nwg * WROWS * ks;
     for (int k = 0; j + k * nwg < bt; ++k) {           // workgroup-uniform
         const int rho = j + k * nwg;
         float* gin = w_bstack + (3 * k + (par ^ 1)) * DW4;
@@ -656,13 +672,13 @@ __device__ __forceinline__ void ws_stack_bwd_post(const WsBwdArgs& a, int t, int
         const float* act = w_act + 64 * k;
         for (int e = tid; e < nwg * (ks >> 2); e += NTH) {
             const int jj = e / (ks >> 2), o = (e - jj * (ks >> 2)) * 4;
-            st4(xp + jj * ks + o, ld4_sc1(a.xpart, (((long long)jj * WROWS + rho) * ks + o) * 4));
+            st4(xp + jj * ks + o, ld4_sc1(xpart, (((long long)jj * WROWS + rho) * ks + o) * 4));
         }
         __syncthreads();
         if (tid < ks) {
             float v = 0.f;
             for (int jj = 0; jj < nwg; ++jj) v += xp[jj * ks + tid];
-            a.dXS[(base + rho) * ks + tid] = v;
+            a.dXS[prow(base, rho, rp) * ks + tid] = v;
             if (tid < W) gin[tid] += v;                // the stack top fed layer 0
         }
         __syncthreads();
@@ -704,7 +720,7 @@ __device__ __forceinline__ void ws_stack_bwd_post(const WsBwdArgs& a, int t, int
             w_dc[tid] = v;
         }
         __syncthreads();
-        if (tid < (ldcs >> 2)) st4_sc1(a.DCS, ((base + rho) * ldcs + 4 * tid) * 4, ld4(w_dc + 4 * tid));      // handed to the group
+        if (tid < (ldcs >> 2)) st4_sc1(a.DCS, (prow(base, rho, rp) * ldcs + 4 * tid) * 4, ld4(w_dc + 4 * tid));      // handed to the group
     }
 }
 
@@ -712,7 +728,10 @@ template <int H, int KS, int L, int NR>
 __global__ __launch_bounds__(NTH) void k_seq_bwd_ws(const WsBwdArgs a)
 {
     constexpr int KH = H / 32, NWG = H / 16, H3 = 3 * H;
-    const int j = blockIdx.x;
+    const int rep = blockIdx.x / NWG, j = blockIdx.x - rep * NWG;
+    const Rep rp{rep, a.R};
+    const int Bl = rows_of(a.B, rp);                    // rows of this replica
+    const float* xpart = a.xpart + (long long)rep * NWG * WROWS * KS;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n = lane & 15, g = lane >> 4;
     if (tid == 0) {
@@ -752,19 +771,19 @@ __global__ __launch_bounds__(NTH) void k_seq_bwd_ws(const WsBwdArgs a)
     for (int e = tid; e < BSTACK_FLOATS; e += NTH) w_bstack[e] = 0.f;
     __syncthreads();
     WSTAMP_INIT();
-    int* ctr = a.ctr;
+    int* ctr = a.ctr + (long long)rep * (L + 1) * CTR_STRIDE;
 
     // the gate threads' operands (saved gates, previous hidden, incoming top gradient): by LDS-DMA, ahead of the waits
     auto prefetch = [&](int l, int t, int bt) {
         if (tid < 4 * WROWS && (tid >> 2) < bt) {
             float* dst = w_pf + 256 * wave;
-            const long long row = (long long)l * a.NT + w_off[t] + (tid >> 2);
+            const long long row = (long long)l * a.NT + prow(w_off[t], tid >> 2, rp);
             const int u = 16 * j + 4 * (tid & 3);
             const float* gt = a.gates + row * 4 * H + u;
 #pragma unroll
             for (int q = 0; q < 4; ++q) __builtin_amdgcn_global_load_lds(gt + q * H, PPK_LDS_PTR(dst + q * 512), 16, 0, 0);
             __builtin_amdgcn_global_load_lds(a.HP + row * H + u, PPK_LDS_PTR(dst + 4 * 512), 16, 0, 0);
-            if (l == L - 1) __builtin_amdgcn_global_load_lds(a.dHtop + (w_off[t] + (tid >> 2)) * H + u, PPK_LDS_PTR(dst + 5 * 512), 16, 0, 0);
+            if (l == L - 1) __builtin_amdgcn_global_load_lds(a.dHtop + prow(w_off[t], tid >> 2, rp) * H + u, PPK_LDS_PTR(dst + 5 * 512), 16, 0, 0);
         }
     };
     // sums of the K-chunk partials (slot 0: accD, slot 1: accC) into w_red
@@ -802,7 +821,7 @@ __global__ __launch_bounds__(NTH) void k_seq_bwd_ws(const WsBwdArgs a)
         for (int rt = 0; rt < NR; ++rt)
             if (rt < ntile) {
                 const int r = 16 * rt + n < rows ? 16 * rt + n : rows - 1;
-                const long long bo = ((rowbase + r) * H3 + wave * 4 * KH) * 4;
+                const long long bo = (prow(rowbase, r, rp) * H3 + wave * 4 * KH) * 4;
                 float b0[KH], b1[KH], b2[KH];
                 if (q0 <= 0 && 0 < q1) load_b<KH>(b0, a.DGH, bo, g);
                 if (q0 <= 1 && 1 < q1) load_b<KH>(b1, a.DGH, bo + 4LL * H, g);
@@ -823,8 +842,10 @@ __global__ __launch_bounds__(NTH) void k_seq_bwd_ws(const WsBwdArgs a)
         for (int rt = 0; rt < NR; ++rt) accK[rt] = f32x4{0.f, 0.f, 0.f, 0.f};
     };
 
-    for (int t = a.T - 1, kstep = 0; t >= 0; --t, ++kstep) {
-        const int bt = a.bs[t], nn = t + 1 < a.T ? a.bs[t + 1] : 0, nrt = (bt + 15) >> 4, nrtn = (nn + 15) >> 4;
+    int kstep = 0;                                     // steps this replica has run (its rows start at its own longest sequence)
+    for (int t = a.T - 1; t >= 0; --t) {
+        const int bt = rows_of(a.bs[t], rp), nn = t + 1 < a.T ? rows_of(a.bs[t + 1], rp) : 0, nrt = (bt + 15) >> 4, nrtn = (nn + 15) >> 4;
+        if (bt == 0) continue;
         const long long base = w_off[t], nbase = w_off[t + 1];
         f32x4 accD[NR], accC[NR];
         auto zero = [&](f32x4 (&x)[NR]) {
@@ -843,7 +864,7 @@ __global__ __launch_bounds__(NTH) void k_seq_bwd_ws(const WsBwdArgs a)
             for (int rt = 0; rt < NR; ++rt)
                 if (rt < nrtn) {
                     const int r = 16 * rt + n < nn ? 16 * rt + n : nn - 1;
-                    const long long bo = ((nbase + r) * a.ldcs + wave * 4 * kc + g * kc) * 4;
+                    const long long bo = (prow(nbase, r, rp) * a.ldcs + wave * 4 * kc + g * kc) * 4;
                     if (kc == 2) {
                         const f32x2 v = ld2_sc1(a.DCS, bo);
                         accD[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wc[0], v[0], accD[rt], 0, 0, 0);
@@ -873,7 +894,7 @@ __global__ __launch_bounds__(NTH) void k_seq_bwd_ws(const WsBwdArgs a)
                         float* cp = w_carry + ((l + 1) * WROWS + row) * 16 + 4 * u4;
                         st4(cp, ld4(cp) + ld4(w_red + (WROWS + row) * 16 + 4 * u4));
                         // layer l + 1 read h_l * drop_l: its input gradient comes back through the same factors
-                        if (a.drop) dsum *= ld4(a.drop + ((long long)l * a.NT + base + row) * H + u);
+                        if (a.drop) dsum *= ld4(a.drop + ((long long)l * a.NT + prow(base, row, rp)) * H + u);
                     }
                     float* cl = w_carry + (l * WROWS + row) * 16 + 4 * u4;
                     const f32x4 dh = dsum + ld4(cl);
@@ -886,7 +907,7 @@ __global__ __launch_bounds__(NTH) void k_seq_bwd_ws(const WsBwdArgs a)
                         dnr[k] = dn[k] * rr[k];
                         c[k] = dh[k] * zz[k];
                     }
-                    const long long o = ((((long long)l * a.NT + base + row) * 3) * H + u) * 4;
+                    const long long o = ((((long long)l * a.NT + prow(base, row, rp)) * 3) * H + u) * 4;
                     st4_sc1(a.DGI, o, dr); st4_sc1(a.DGI, o + 4LL * H, dz); st4_sc1(a.DGI, o + 8LL * H, dn);
                     st4_sc1(a.DGH, o, dr); st4_sc1(a.DGH, o + 4LL * H, dz); st4_sc1(a.DGH, o + 8LL * H, dnr);
                     st4(cl, c);
@@ -916,7 +937,7 @@ __global__ __launch_bounds__(NTH) void k_seq_bwd_ws(const WsBwdArgs a)
                 for (int rt = 0; rt < NR; ++rt)
                     if (rt < nrt) {
                         const int r = 16 * rt + n < bt ? 16 * rt + n : bt - 1;
-                        const long long bo = ((base + r) * H3 + wave * 4 * KH) * 4;
+                        const long long bo = (prow(base, r, rp) * H3 + wave * 4 * KH) * 4;
                         // every load of the row tile goes out before its first MFMA: one memory round trip, not four
                         float b0[KH], b1[KH], b2[KH], b3[KH];
                         load_b<KH>(b0, gi, bo, g);                          // dr
@@ -943,16 +964,16 @@ __global__ __launch_bounds__(NTH) void k_seq_bwd_ws(const WsBwdArgs a)
 #pragma unroll
                     for (int mm = 0; mm < 4; ++mm) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wxa[q][mm], gv[mm], acc, 0, 0, 0);
                 }
-                if (16 * rt + n < bt) st4_sc1(a.xpart, (((long long)j * WROWS + 16 * rt + n) * KS + 16 * ot + 4 * g) * 4, acc);
+                if (16 * rt + n < bt) st4_sc1(xpart, (((long long)j * WROWS + 16 * rt + n) * KS + 16 * ot + 4 * g) * 4, acc);
             }
         }
         WSTAMP(6);
         group_signal(ctr);
         WSTAMP(7);
-        ws_stack_bwd_pre(a, t, kstep, j, NWG);
+        ws_stack_bwd_pre(a, t, kstep, j, NWG, rp);
         if (!ws_wait(ctr, NWG * (kstep + 1), a.status, &w_flag)) return;
         WSTAMP(11);
-        ws_stack_bwd_post(a, t, kstep, j, NWG, KS);
+        ws_stack_bwd_post(a, t, kstep, j, NWG, KS, rp);
         WSTAMP(8);
         group_signal(ctr + L * CTR_STRIDE);
         WSTAMP(9);
@@ -967,22 +988,23 @@ __global__ __launch_bounds__(NTH) void k_seq_bwd_ws(const WsBwdArgs a)
             carry0_finish(bt, nrt);
         }
         WSTAMP(10);
+        ++kstep;
     }
     // the stack of step 0 read the INITIAL hidden state of the top layer: dh0[L-1] += DCS_0 . [W_c ; W_s]
     {
         if (have_k) {
-            carry0_part(2, 3, a.B, 0, (a.B + 15) >> 4);
-            carry0_finish(a.B, (a.B + 15) >> 4);
+            carry0_part(2, 3, Bl, 0, (Bl + 15) >> 4);
+            carry0_finish(Bl, (Bl + 15) >> 4);
         }
-        if (!ws_wait(ctr + L * CTR_STRIDE, NWG * a.T, a.status, &w_flag)) return;
+        if (!ws_wait(ctr + L * CTR_STRIDE, NWG * kstep, a.status, &w_flag)) return;
         f32x4 accD[NR];
-        const int kc = a.ldcs >> 5, nrt = (a.B + 15) >> 4;
+        const int kc = a.ldcs >> 5, nrt = (Bl + 15) >> 4;
 #pragma unroll
         for (int rt = 0; rt < NR; ++rt) {
             accD[rt] = f32x4{0.f, 0.f, 0.f, 0.f};
             if (rt < nrt) {
-                const int r = 16 * rt + n < a.B ? 16 * rt + n : a.B - 1;
-                const long long bo = (((long long)r) * a.ldcs + wave * 4 * kc + g * kc) * 4;
+                const int r = 16 * rt + n < Bl ? 16 * rt + n : Bl - 1;
+                const long long bo = (prow(0, r, rp) * a.ldcs + wave * 4 * kc + g * kc) * 4;
                 if (kc == 2) {
                     const f32x2 v = ld2_sc1(a.DCS, bo);
                     accD[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wc[0], v[0], accD[rt], 0, 0, 0);
@@ -992,13 +1014,13 @@ __global__ __launch_bounds__(NTH) void k_seq_bwd_ws(const WsBwdArgs a)
                 }
             }
         }
-        reduce(accD, accD, 1, nrt, a.B);
+        reduce(accD, accD, 1, nrt, Bl);
         for (int e = tid; e < L * WROWS * 4; e += NTH) {
             const int l = e / (WROWS * 4), row = (e >> 2) & (WROWS - 1), u4 = e & 3;
-            if (row < a.B) {
+            if (row < Bl) {
                 f32x4 v = ld4(w_carry + (l * WROWS + row) * 16 + 4 * u4);
                 if (l == L - 1) v += ld4(w_red + row * 16 + 4 * u4);
-                st4(a.dh0 + ((long long)l * a.B + row) * H + 16 * j + 4 * u4, v);
+                st4(a.dh0 + ((long long)l * a.B + prow(0, row, rp)) * H + 16 * j + 4 * u4, v);
             }
         }
     }
@@ -1052,22 +1074,64 @@ WsKernel pick_fwd(int H, int ks, int L, int nr)
     return nullptr;
 }
 
+// auto mode takes these kernels up to this many sequences per call (PPK_WS_MAX_ROWS in the environment; default: whenever one launch fits)
+int g_ws_max_rows = -1;
+int ws_auto_max_rows()
+{
+    if (g_ws_max_rows < 0) { const char* e = getenv("PPK_WS_MAX_ROWS"); g_ws_max_rows = e ? atoi(e) : (1 << 30); }
+    return g_ws_max_rows;
+}
+
+// How a batch is dealt to replicas on the current device: as many replicas of at most 16 rows (one row tile: the faster
+// kernels) as the CUs allow — a replica is H / 16 workgroups, one per CU, all resident at once —, else replicas of at most
+// 32 rows.  false: the batch does not fit one launch.
+bool ws_plan(int64_t B, int64_t H, int& R, int& nr)
+{
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return false;
+    const int64_t nwg = H / 16, rmax = cus / nwg;
+    if (B < 1 || rmax < 1) return false;
+    int64_t r = std::min<int64_t>((B + 15) / 16, rmax);
+    const int64_t rows = (B + r - 1) / r;
+    if (rows > WROWS) return false;
+    R = (int)r;
+    nr = rows > 16 ? 2 : 1;
+    return true;
+}
+
 }  // namespace
 
 namespace ppk {
+
+// auto mode: wherever one launch of replicas fits the device these kernels are ~2 x faster than either other schedule
+// (H 512: up to 256 sequences, H 256: up to 512; tools/ws_replica_shapes.py, profiles/r03_ws_replicas.txt)
+bool seq_auto_ws(int64_t B, int64_t H, int R)
+{
+    (void)H;
+    return R >= 1 && B <= ws_auto_max_rows();
+}
+
+size_t seq_fwd_ws_ws_bytes(int64_t B, int64_t H, int64_t L, int64_t W)
+{
+    int R = 1, nr = 1;
+    if (H % 16 || L > WS_MAXL || !ws_plan(B, H, R, nr)) return 0;
+    const int64_t ldcs = (3 + W + 31) / 32 * 32, nwg = H / 16;
+    return ppk_align_up(sizeof(float) * (size_t)H * (size_t)ldcs, 256) + ppk_align_up(sizeof(int) * ((size_t)R * (size_t)(L + 1) * CTR_STRIDE + 64), 256)
+           + ppk_align_up(sizeof(float) * (size_t)R * (size_t)nwg * WROWS * (size_t)ldcs, 256);
+}
 
 bool seq_fwd_ws_ok(int64_t T, int64_t B, int64_t NT, int64_t H, int64_t L, int64_t W, int64_t D, int64_t ks, int64_t ldcs)
 {
     const int mode = seq_persist_mode(-2);
     if (mode != 2 && mode != -1) return false;
-    if (T < 1 || T > MAXT || B < 1 || B > WROWS || L < 1 || L > WS_MAXL || NT >= (1LL << 24)) return false;
+    if (T < 1 || T > MAXT || B < 1 || L < 1 || L > WS_MAXL || H % 16 || L * NT * 4 * H * 4 >= (1LL << 31)) return false;      // byte offsets of the buffer accesses
     if (ldcs != (3 + W + 31) / 32 * 32 || ks != (W + 31) / 32 * 32 || ldcs > 64) return false;
-    if (!pick_fwd((int)H, (int)ks, (int)L, B > 16 ? 2 : 1)) return false;
+    int R, nr;
+    if (!ws_plan(B, H, R, nr)) return false;            // every workgroup resident at once, one per CU
+    if (mode == -1 && !seq_auto_ws(B, H, R)) return false;
+    if (!pick_fwd((int)H, (int)ks, (int)L, nr)) return false;
     const int64_t nwg = H / 16, nown = (WROWS + nwg - 1) / nwg, DW4 = (D * W + 3) / 4 * 4;
-    if (nown * 2 * DW4 > STACK_FLOATS) return false;
-    int dev = 0, cus = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return false;
-    return cus >= nwg;                                  // every workgroup resident at once, one per CU
+    return nown * 2 * DW4 <= STACK_FLOATS;
 }
 
 int seq_fwd_ws(int64_t T, const int64_t* bs, int64_t B, int64_t NT, int64_t V, int64_t H, int64_t L, int64_t W, int64_t D,
@@ -1077,11 +1141,13 @@ int seq_fwd_ws(int64_t T, const int64_t* bs, int64_t B, int64_t NT, int64_t V, i
                float* XS, float* Hs, float* HP, float* gates, float* S, float* CS, int64_t ldcs,
                const float* drop, float* Hdrop, void* ws, size_t ws_bytes, hipStream_t stream)
 {
-    if (ws_bytes < seq_fwd_persist_ws_bytes(B, H, L, W)) PPK_FAIL(PPK_ERR_WS, "seq_fwd_ws: workspace too small");
-    WsKernel kern = pick_fwd((int)H, (int)ks, (int)L, B > 16 ? 2 : 1);
+    if (ws_bytes < seq_fwd_ws_ws_bytes(B, H, L, W)) PPK_FAIL(PPK_ERR_WS, "seq_fwd_ws: workspace too small");
+    int R = 1, nr = 1;
+    if (!ws_plan(B, H, R, nr)) PPK_FAIL(PPK_ERR_UNSUP, "seq_fwd_ws: the batch does not fit one launch");
+    WsKernel kern = pick_fwd((int)H, (int)ks, (int)L, nr);
     if (!kern) PPK_FAIL(PPK_ERR_UNSUP, "seq_fwd_ws: unsupported shape");
     WsArgs a{};
-    a.T = (int)T; a.B = (int)B; a.W = (int)W; a.D = (int)D; a.V = (int)V; a.ldcs = (int)ldcs; a.DW = (int)(D * W);
+    a.T = (int)T; a.B = (int)B; a.W = (int)W; a.D = (int)D; a.V = (int)V; a.ldcs = (int)ldcs; a.DW = (int)(D * W); a.R = R;
     a.NT = NT;
     a.tokens = tokens; a.table = table; a.wx0s = wx0s;
     for (int l = 0; l < (int)L; ++l) { a.w_ih[l] = w_ih[l]; a.w_hh[l] = w_hh[l]; a.b_ih[l] = b_ih[l]; a.b_hh[l] = b_hh[l]; }
@@ -1092,21 +1158,20 @@ int seq_fwd_ws(int64_t T, const int64_t* bs, int64_t B, int64_t NT, int64_t V, i
     a.dbg = g_ws_dbg;
 #endif
     for (int t = 0; t < (int)T; ++t) a.bs[t] = (int)bs[t];
-    // the same carve as the row-block persistent kernel with one group (seq_fwd_persist_ws_bytes covers it)
     const int nwg = (int)(H / 16);
     char* cur = (char*)ws;
     float* wcs_t = (float*)ppk_carve(cur, sizeof(float) * (size_t)H * (size_t)ldcs);
-    const size_t nctr = (size_t)(L + 1) * CTR_STRIDE + 64;
+    const size_t nctr = (size_t)R * (size_t)(L + 1) * CTR_STRIDE + 64;
     int* ctr = (int*)ppk_carve(cur, sizeof(int) * nctr);
-    a.wcs_t = wcs_t; a.ctr = ctr; a.status = ctr + (size_t)(L + 1) * CTR_STRIDE;
-    a.hpart = (float*)ppk_carve(cur, sizeof(float) * (size_t)nwg * WROWS * (size_t)ldcs);
+    a.wcs_t = wcs_t; a.ctr = ctr; a.status = ctr + (size_t)R * (size_t)(L + 1) * CTR_STRIDE;
+    a.hpart = (float*)ppk_carve(cur, sizeof(float) * (size_t)R * (size_t)nwg * WROWS * (size_t)ldcs);
     PPK_HIP(hipMemsetAsync(ctr, 0, sizeof(int) * nctr, stream));
     k_ws_wcs_transpose<<<dim3((unsigned)std::min<int64_t>((H * ldcs + 255) / 256, 1024)), dim3(256), 0, stream>>>(wcs, (int)(3 + W), (int)H, (int)ldcs, wcs_t);
     PPK_CHECK_LAUNCH("k_ws_wcs_transpose");
     {
         const double flops = 2.0 * (double)NT * 3.0 * (double)H * ((double)ks + (2.0 * (double)L - 1.0) * (double)H);
         ProfScope prof(PK_SEQ_FWD, flops, stream);
-        kern<<<dim3((unsigned)nwg), dim3(NTH), 0, stream>>>(a);
+        kern<<<dim3((unsigned)(R * nwg)), dim3(NTH), 0, stream>>>(a);
         PPK_CHECK_LAUNCH("k_seq_fwd_ws");
     }
     float* ptrs[5] = {Hs, CS, XS, S, a.drop ? Hdrop : nullptr};
@@ -1114,19 +1179,27 @@ int seq_fwd_ws(int64_t T, const int64_t* bs, int64_t B, int64_t NT, int64_t V, i
     return seq_poison(a.status, ptrs, counts, 5, stream);
 }
 
+size_t seq_bwd_ws_ws_bytes(int64_t B, int64_t H, int64_t L, int64_t W)
+{
+    int R = 1, nr = 1;
+    if (H % 16 || L > WS_MAXL || !ws_plan(B, H, R, nr)) return 0;
+    const int64_t ks = (W + 31) / 32 * 32, nwg = H / 16;
+    return ppk_align_up(sizeof(int) * ((size_t)R * (size_t)(L + 1) * CTR_STRIDE + 64), 256) + ppk_align_up(sizeof(float) * (size_t)R * (size_t)nwg * WROWS * (size_t)ks, 256);
+}
+
 bool seq_bwd_ws_ok(int64_t T, int64_t B, int64_t NT, int64_t H, int64_t L, int64_t W, int64_t D, int64_t ks, int64_t ldcs)
 {
     const int mode = seq_persist_mode(-2);
     if (mode != 2 && mode != -1) return false;
-    if (T < 1 || T > MAXT || B < 1 || B > WROWS || L < 1 || L > WS_MAXL || NT >= (1LL << 24)) return false;
+    if (T < 1 || T > MAXT || B < 1 || L < 1 || L > WS_MAXL || H % 16) return false;
     if (ldcs != (3 + W + 31) / 32 * 32 || ks != (W + 31) / 32 * 32 || ldcs > 64) return false;
     if (NT * 3 * H * 4 * L >= (1LL << 31)) return false;              // byte offsets of the buffer accesses into DGI / DGH
-    if (!pick_bwd((int)H, (int)ks, (int)L, B > 16 ? 2 : 1)) return false;
+    int R, nr;
+    if (!ws_plan(B, H, R, nr)) return false;
+    if (mode == -1 && !seq_auto_ws(B, H, R)) return false;
+    if (!pick_bwd((int)H, (int)ks, (int)L, nr)) return false;
     const int64_t nwg = H / 16, nown = (WROWS + nwg - 1) / nwg, DW4 = (D * W + 3) / 4 * 4;
-    if (nown * 3 * DW4 > BSTACK_FLOATS) return false;
-    int dev = 0, cus = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return false;
-    return cus >= nwg;
+    return nown * 3 * DW4 <= BSTACK_FLOATS;
 }
 
 int seq_bwd_ws(int64_t T, const int64_t* bs, int64_t B, int64_t NT, int64_t H, int64_t L, int64_t W, int64_t D,
@@ -1135,11 +1208,13 @@ int seq_bwd_ws(int64_t T, const int64_t* bs, int64_t B, int64_t NT, int64_t H, i
                const float* dHtop, float* dXS, int64_t ks, float* DGI, float* DGH, float* DCS, float* dh0,
                const float* drop, void* ws, size_t ws_bytes, hipStream_t stream)
 {
-    if (ws_bytes < seq_bwd_persist_ws_bytes(B, H, L, W, D)) PPK_FAIL(PPK_ERR_WS, "seq_bwd_ws: workspace too small");
-    WsBwdKernel kern = pick_bwd((int)H, (int)ks, (int)L, B > 16 ? 2 : 1);
+    if (ws_bytes < seq_bwd_ws_ws_bytes(B, H, L, W)) PPK_FAIL(PPK_ERR_WS, "seq_bwd_ws: workspace too small");
+    int R = 1, nr = 1;
+    if (!ws_plan(B, H, R, nr)) PPK_FAIL(PPK_ERR_UNSUP, "seq_bwd_ws: the batch does not fit one launch");
+    WsBwdKernel kern = pick_bwd((int)H, (int)ks, (int)L, nr);
     if (!kern) PPK_FAIL(PPK_ERR_UNSUP, "seq_bwd_ws: unsupported shape");
     WsBwdArgs a{};
-    a.T = (int)T; a.B = (int)B; a.W = (int)W; a.D = (int)D; a.ldcs = (int)ldcs; a.DW = (int)(D * W);
+    a.T = (int)T; a.B = (int)B; a.W = (int)W; a.D = (int)D; a.ldcs = (int)ldcs; a.DW = (int)(D * W); a.R = R;
     a.NT = NT;
     for (int l = 0; l < (int)L; ++l) { a.w_ih_t[l] = w_ih_t[l]; a.w_hh_t[l] = w_hh_t[l]; }
     a.wcs_t = wcs_t;
@@ -1150,20 +1225,17 @@ int seq_bwd_ws(int64_t T, const int64_t* bs, int64_t B, int64_t NT, int64_t H, i
     a.dbg = g_ws_dbg ? g_ws_dbg + 16 * 64 : nullptr;
 #endif
     for (int t = 0; t < (int)T; ++t) a.bs[t] = (int)bs[t];
-    // the carve of the row-block persistent backward with one group (its first block, the k-major copy of the stack
-    // columns of W_ih0, is not needed here: the registers are loaded from w_ih_t[0] directly)
     const int nwg = (int)(H / 16);
     char* cur = (char*)ws;
-    (void)ppk_carve(cur, sizeof(float) * (size_t)3 * H * ks);
-    const size_t nctr = (size_t)(L + 1) * CTR_STRIDE + 64;
+    const size_t nctr = (size_t)R * (size_t)(L + 1) * CTR_STRIDE + 64;
     int* ctr = (int*)ppk_carve(cur, sizeof(int) * nctr);
-    a.ctr = ctr; a.status = ctr + (size_t)(L + 1) * CTR_STRIDE;
-    a.xpart = (float*)ppk_carve(cur, sizeof(float) * (size_t)nwg * WROWS * (size_t)ks);
+    a.ctr = ctr; a.status = ctr + (size_t)R * (size_t)(L + 1) * CTR_STRIDE;
+    a.xpart = (float*)ppk_carve(cur, sizeof(float) * (size_t)R * (size_t)nwg * WROWS * (size_t)ks);
     PPK_HIP(hipMemsetAsync(ctr, 0, sizeof(int) * nctr, stream));
     {
         const double flops = 2.0 * (double)NT * (double)H * (3.0 * (double)H * (2.0 * (double)L - 1.0) + (double)ldcs) + 2.0 * (double)NT * 3.0 * (double)H * (double)ks;
         ProfScope prof(PK_SEQ_BWD, flops, stream);
-        kern<<<dim3((unsigned)nwg), dim3(NTH), 0, stream>>>(a);
+        kern<<<dim3((unsigned)(R * nwg)), dim3(NTH), 0, stream>>>(a);
         PPK_CHECK_LAUNCH("k_seq_bwd_ws");
     }
     float* ptrs[5] = {dXS, DGI, DGH, DCS, dh0};

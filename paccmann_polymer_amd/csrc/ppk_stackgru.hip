@@ -221,7 +221,7 @@ size_t ppk_stackgru_seq_fwd_workspace_bytes(int64_t B, int64_t H, int64_t L, int
     if (B < 1 || H < 1 || L < 1 || W < 1) return 0;
     const int64_t ldcs = (3 + W + 31) / 32 * 32;
     return (size_t)L * ppk_align_up(sizeof(float) * (size_t)B * 3 * (size_t)H, 256) + ppk_align_up(sizeof(float) * (size_t)B * (size_t)ldcs, 256)
-           + ppk::seq_fwd_persist_ws_bytes(B, H, L, W);
+           + std::max(ppk::seq_fwd_persist_ws_bytes(B, H, L, W), ppk::seq_fwd_ws_ws_bytes(B, H, L, W));
 }
 
 // table [V, 3H]  = emb . W_ih0[:, :E]^T + b_ih0      (embedding half of the layer-0 input product)
@@ -326,7 +326,8 @@ int ppk_stackgru_seq_fwd(int64_t T, const int64_t* batch_sizes_host, int64_t B, 
 size_t ppk_stackgru_seq_bwd_workspace_bytes(int64_t B, int64_t H, int64_t L, int64_t W, int64_t D)
 {
     if (B < 1 || H < 1 || L < 1 || W < 1 || D < 1) return 0;
-    return std::max(2 * ppk_align_up(sizeof(float) * (size_t)B * (size_t)D * (size_t)W, 256), ppk::seq_bwd_persist_ws_bytes(B, H, L, W, D));
+    return std::max(std::max(2 * ppk_align_up(sizeof(float) * (size_t)B * (size_t)D * (size_t)W, 256), ppk::seq_bwd_persist_ws_bytes(B, H, L, W, D)),
+                    ppk::seq_bwd_ws_ws_bytes(B, H, L, W));
 }
 
 // dHtop [NT, H]: gradient arriving at the top layer's output of every step

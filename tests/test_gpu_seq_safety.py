@@ -166,12 +166,13 @@ def test_auto_mode_picks_the_measured_faster_schedule(H, B, persistent):
 
 
 @pytest.mark.parametrize('H,B,mode,single_launch', [
-    (512, 16, -1, True), (512, 32, -1, True), (512, 33, -1, False), (512, 16, 0, False), (512, 7, 2, True), (256, 21, -1, True),
-    (128, 9, 2, True), (96, 9, 2, False),
+    (512, 16, -1, True), (512, 32, -1, True), (512, 33, -1, True), (512, 256, -1, True), (512, 288, -1, False), (512, 16, 0, False), (512, 7, 2, True),
+    (256, 21, -1, True), (256, 500, -1, True), (128, 9, 2, True), (96, 9, 2, False),
 ])
 def test_small_batches_take_the_weights_stationary_kernels(H, B, mode, single_launch):
-    """Up to 32 sequences the whole time loop is ONE launch per pass with the weights resident in registers
-    (ppk_seq_ws.hip; reported under the k_seq_fwd / k_seq_bwd profiling kinds) in auto mode and mode 2; beyond 32 rows,
+    """Where one launch of replicas (<= 32 sequences each, H / 16 workgroups each, one workgroup per CU) fits the device the
+    whole time loop is ONE launch per pass with the weights resident in registers (ppk_seq_ws.hip; reported under the
+    k_seq_fwd / k_seq_bwd profiling kinds) in auto mode and mode 2: H 512 up to 256 sequences, H 256 up to 512; beyond that,
     in mode 0 and at hidden sizes without an instantiation the per-step launches run."""
     kinds = _seq_kernels_launched(H, B, mode=mode, W=10 if H <= 128 else 40)      # H >= 256 is instantiated for 64 stack columns only
     assert ('k_seq_fwd' in kinds) == single_launch, (H, B, sorted(kinds))

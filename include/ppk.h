@@ -158,11 +158,13 @@ int64_t ppk_nt_small_grid_limit(int64_t limit);
 
 /* Launch schedule of K1 (ppk_stackgru_seq_fwd / _bwd).  Three schedules compute the same step: the whole time loop as ONE
  * persistent launch per pass over row-block groups (64 rows x H / 32 workgroups, synchronised among their own workgroups
- * only, weights streamed), one launch per layer-step, and — for at most 32 sequences, the reference's own regime of one
- * <= 21-SMILES bundle per optimizer step (reactions_vae.py:52-59) — ONE launch per pass of H / 16 workgroups that keep
- * their rows of every weight matrix in registers for the whole launch (ppk_seq_ws.hip).  mode:
- *   -1  auto (default; PPK_SEQ_PERSIST in the environment): the weights-stationary launch up to 32 sequences where the
- *       shape is instantiated (below); the row-block persistent launch where it is faster on MI355X — when the batch's
+ * only, weights streamed), one launch per layer-step, and — for small and medium batches, first of all the reference's own
+ * regime of one <= 21-SMILES bundle per optimizer step (reactions_vae.py:52-59) — ONE launch per pass of replicas of <= 16 (32)
+ * sequences, each H / 16 workgroups that keep their rows of every weight matrix in registers for the whole launch
+ * (ppk_seq_ws.hip).  mode:
+ *   -1  auto (default; PPK_SEQ_PERSIST in the environment): the weights-stationary launch wherever the shape is instantiated
+ *       and one launch fits the device (below: H 512 up to 256 sequences, H 256 up to 512; PPK_WS_MAX_ROWS in the environment
+ *       lowers that); the row-block persistent launch where it is faster on MI355X — when the batch's
  *       row-block groups make one machine-full that is at least 3/8 full at H >= 384
  *       (9/10 at H >= 256) or two that are at least 9/10 full at H >= 512: e.g. H 512 from batch 1024 to 4096, H 256 at batch
  *       4096, never at H 128 (tools/persist_threshold_shapes.py, profiles/r03_persist_shapes.txt) —, per-step launches elsewhere;
@@ -171,10 +173,11 @@ int64_t ppk_nt_small_grid_limit(int64_t limit);
  *       roundup32(W) / roundup32(3 + W), one group's workgroups resident together on the current device); an
  *       unsupported shape takes the per-step launches.  Never the weights-stationary kernels;
  *    2  like auto (the value the tests use to say "the weights-stationary kernels where they exist").
- * Weights-stationary shapes: B <= 32, L <= 2, H in {32, 64, 128, 256, 512} with ks == ldcs-minimal paddings, ldcs <= 64
+ * Weights-stationary shapes: ceil(B / 16) replicas (fewer, of up to 32 rows, when replicas x H / 16 would exceed the CUs), L <= 2, H in {32, 64, 128, 256, 512} with ks == ldcs-minimal paddings, ldcs <= 64
  * (H >= 256: ks == 64 only), the owned rows' stacks within the workgroup's LDS (32 / (H / 16) rows x D x W floats: 2 images
- * forward, 3 backward), at least H / 16 CUs.  fp32 operands whatever ppk_mfma_mode says.  Measured (MI355X, H 512, L 2,
- * bundles of 6 - 21 sequences of 20 - 100 tokens, whole training step): 15.7 ms -> 8.3 ms (profiles/r03_small_batch_ws.txt).
+ * forward, 3 backward).  fp32 operands whatever ppk_mfma_mode says.  Measured (MI355X, H 512, L 2,
+ * bundles of 6 - 21 sequences of 20 - 100 tokens, whole training step): 15.5 ms -> 8.1 ms (profiles/r03_small_batch_ws.txt); batch 64: 17.2 -> 9.0 ms, 256: 19.9 -> 12.9 ms
+ * (profiles/r03_ws_replicas.txt).
  * Any other value only queries.  Process-global like ppk_nt_small_grid_limit.  Returns the value in force.
  * A persistent launch (either kind) whose workgroups lose a hand-off (bounded wait, ~3 s; another process holding the GPU can cause
  * it) fills every output of the call with NaN: the entry point still returns PPK_OK (it never synchronises). */

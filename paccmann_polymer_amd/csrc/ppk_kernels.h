@@ -78,6 +78,15 @@ int seq_fwd_ws(int64_t T, const int64_t* bs, int64_t B, int64_t NT, int64_t V, i
                float* XS, float* Hs, float* HP, float* gates, float* S, float* CS, int64_t ldcs,
                const float* drop, float* Hdrop, void* ws, size_t ws_bytes, hipStream_t stream);
 
+// looped forward (mode 3, experiment): replicas of up to 256 rows walked 32 at a time, weights in registers
+size_t seq_fwd_wsl_ws_bytes(int64_t B, int64_t H, int64_t L, int64_t W);
+bool seq_fwd_wsl_ok(int64_t T, int64_t B, int64_t NT, int64_t H, int64_t L, int64_t W, int64_t D, int64_t ks, int64_t ldcs);
+int seq_fwd_wsl(int64_t T, const int64_t* bs, int64_t B, int64_t NT, int64_t V, int64_t H, int64_t L, int64_t W, int64_t D,
+                const int64_t* tokens, const float* table, const float* wx0s, int64_t ks,
+                const float* const* w_ih, const float* const* w_hh, const float* const* b_ih, const float* const* b_hh,
+                const float* wcs, const float* bcs, const float* h0, const float* S0,
+                float* XS, float* Hs, float* HP, float* gates, float* S, float* CS, int64_t ldcs,
+                const float* drop, float* Hdrop, void* ws, size_t ws_bytes, hipStream_t stream);
 bool seq_bwd_ws_ok(int64_t T, int64_t B, int64_t NT, int64_t H, int64_t L, int64_t W, int64_t D, int64_t ks, int64_t ldcs);
 int seq_bwd_ws(int64_t T, const int64_t* bs, int64_t B, int64_t NT, int64_t H, int64_t L, int64_t W, int64_t D,
                const float* const* w_ih_t, const float* const* w_hh_t, const float* wcs_t,

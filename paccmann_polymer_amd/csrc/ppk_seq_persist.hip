@@ -660,7 +660,7 @@ int mfma_mode(int mode)
 
 int seq_persist_mode(int mode)
 {
-    if (mode >= -1 && mode <= 2) g_force = mode;
+    if (mode >= -1 && mode <= 3) g_force = mode;
     return force_mode();
 }
 

@@ -130,6 +130,7 @@ __device__ __forceinline__ bool ws_wait(int* ctr, int target, int* status, volat
 // the four k-groups of a batch row read ADJACENT 16-byte pieces in one load instruction — 64 contiguous bytes per row and
 // instruction (16 line requests per wave instruction instead of 32, each line asked for once per two instructions instead
 // of four times): k = 16 x + 4 g + c for m = 4 x + c.  The weight registers use the same map.
+template <int N> struct IntK { static constexpr int v = N; };
 template <int KK> __device__ __forceinline__ constexpr int wk(int g, int m)
 {
     return KK % 4 == 0 ? 16 * (m >> 2) + 4 * g + (m & 3) : g * KK + m;
@@ -552,6 +553,268 @@ __global__ __launch_bounds__(NTH) void k_seq_fwd_ws(const WsArgs a)
         }
     }
     WSTAMP_DUMP(a.dbg, j);
+}
+
+// =====================================================================================================================
+// Looped forward: replicas of up to 256 rows (8 per workgroup's stack ownership), the rows of a replica walked 32 at a
+// time inside every layer phase — the weights stay in registers, three hand-offs per timestep for the whole replica.
+// B = 2048 at H 512 is 8 replicas x 256 rows on 256 CUs: no weight is streamed at all.  The owned rows' stacks do not fit
+// LDS here: the previous row comes from global S (this workgroup's own stores of the step before).
+constexpr int LROWS = 256;                     // rows of a replica
+constexpr int LOWN = 8;                        // stack rows a workgroup owns (rows of a replica <= 8 x H / 16)
+__shared__ __align__(16) float l_hown[WS_MAXL * LROWS * 16];    // this workgroup's 16 units of every layer's hidden state
+__shared__ __align__(16) float l_sp[LOWN * 128];                // first 2W elements of the owned rows' previous stack rows
+__shared__ __align__(16) float l_act[LOWN * 64];
+__shared__ __align__(16) float l_top[LOWN * 64];
+
+template <int H, int KS, int L>
+__global__ __launch_bounds__(NTH) void k_seq_fwd_wsl(const WsArgs a)
+{
+    constexpr int KH = H / 32, KX = KS / 32, NWG = H / 16, NR = 2;
+    const int rep = blockIdx.x / NWG, j = blockIdx.x - rep * NWG;
+    const Rep rp{rep, a.R};
+    const int Bl = rows_of(a.B, rp);
+    float* hpart = a.hpart + (long long)rep * NWG * LROWS * a.ldcs;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n = lane & 15, g = lane >> 4;
+    const long long H3 = 3LL * H;
+    const int ldcs = a.ldcs, W = a.W, DW = a.DW, nout = 3 + W;
+    if (tid == 0) {
+        int s = 0;
+        for (int t = 0; t < a.T; ++t) { w_off[t] = s; s += a.bs[t]; }
+        w_off[a.T] = s;
+    }
+    float wh[L][3][KH], wi0[3][KX], wi[L > 1 ? L - 1 : 1][3][KH], wc[4];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        const long long grow = (long long)q * H + 16 * j + n;
+        load_w<KX>(wi0[q], a.wx0s, grow, wave, lane);
+#pragma unroll
+        for (int l = 0; l < L; ++l) load_w<KH>(wh[l][q], a.w_hh[l], grow, wave, lane);
+#pragma unroll
+        for (int l = 1; l < L; ++l) load_w<KH>(wi[l - 1][q], a.w_ih[l], grow, wave, lane);
+    }
+#pragma unroll
+    for (int m = 0; m < 4; ++m) wc[m] = 16 * (wave & 3) < ldcs ? a.wcs_t[(long long)(16 * j + 4 * g + m) * ldcs + 16 * (wave & 3) + n] : 0.f;
+    for (int e = tid; e < L * LROWS * 4; e += NTH) {
+        const int l = e / (LROWS * 4), row = (e >> 2) & (LROWS - 1), u4 = e & 3;
+        st4(l_hown + (l * LROWS + row) * 16 + 4 * u4,
+            row < Bl ? ld4(a.h0 + ((long long)l * a.B + prow(0, row, rp)) * H + 16 * j + 4 * u4) : f32x4{0.f, 0.f, 0.f, 0.f});
+    }
+    __syncthreads();
+    int* ctr = a.ctr + (long long)rep * (L + 1) * CTR_STRIDE;
+
+    // heads partial of the rows r0 .. r0 + 31 (w_hown layout [row][16 units]); wave = (16-column block of the outputs, row tile)
+    auto heads_pair = [&](int l, int r0, int bt) {
+        const int ot = wave & 3, rt = (wave >> 2) ^ 1, row = r0 + 16 * rt + n;
+        if (16 * ot < ldcs && r0 + 16 * rt < bt) {
+            const f32x4 hv = ld4(l_hown + (l * LROWS + row) * 16 + 4 * g);
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int m = 0; m < 4; ++m) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wc[m], hv[m], acc, 0, 0, 0);
+            if (row < bt) st4_sc1(hpart, (((long long)j * LROWS + row) * ldcs + 16 * ot + 4 * g) * 4, acc);
+        }
+    };
+    for (int r0 = 0; r0 < Bl; r0 += 32) heads_pair(L - 1, r0, Bl);
+    group_signal(ctr + (L - 1) * CTR_STRIDE);
+
+    float* cellv = w_part;
+    // rows r0 .. r0 + 31 of layer l: partial dump, sum in wave order, GRU cell, stores
+    auto epilogue = [&](f32x4 (&acc)[NR][4], int l, int t, int r0, int bt, int nrt) {
+        const long long base = w_off[t];
+#pragma unroll
+        for (int rt = 0; rt < NR; ++rt)
+            if (rt < nrt) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) st4(w_part + ((wave * 4 + q) * WROWS + 16 * rt + n) * 16 + 4 * g, acc[rt][q]);
+            }
+        __syncthreads();
+        {
+            const int q = tid >> 7, row = (tid >> 2) & 31, u4 = tid & 3;
+            if (r0 + row < bt) {
+                const float* p = w_part + (q * WROWS + row) * 16 + 4 * u4;
+                f32x4 v = ld4(p);
+#pragma unroll
+                for (int w = 1; w < 8; ++w) v += ld4(p + w * 4 * WROWS * 16);
+                st4(w_red + (q * WROWS + row) * 16 + 4 * u4, v);
+            }
+        }
+        wait_vmcnt<0>();
+        __syncthreads();
+        if (r0 + (tid >> 4) < bt) {
+            const int e = tid;
+            const float v0 = w_red[e] + (w_pf[e] + w_pf[3 * 512 + e]);
+            const float v1 = w_red[512 + e] + (w_pf[512 + e] + w_pf[4 * 512 + e]);
+            const float v2 = w_red[1024 + e] + w_pf[1024 + e];
+            const float v3 = w_red[1536 + e] + w_pf[5 * 512 + e];
+            float* hl = l_hown + (l * LROWS + r0) * 16 + e;
+            const float hp = *hl;
+            const float rr = sigmoidf_(v0), zz = sigmoidf_(v1);
+            const float nn = tanhf(v2 + rr * v3);
+            *hl = (1.0f - zz) * nn + zz * hp;
+            cellv[e] = hp; cellv[512 + e] = rr; cellv[1024 + e] = zz; cellv[1536 + e] = nn; cellv[2048 + e] = v3;
+        }
+        __syncthreads();
+        if (tid < 4 * WROWS && r0 + (tid >> 2) < bt) {
+            const long long pr = (long long)l * a.NT + prow(base, r0 + (tid >> 2), rp);
+            const int u = 16 * j + 4 * (tid & 3);
+            const f32x4 ho = ld4(l_hown + (l * LROWS + r0) * 16 + 4 * tid);
+            st4_sc1(a.Hs, (pr * H + u) * 4, ho);                                             // handed to the group
+            if (a.drop && l < L - 1) st4_sc1(a.HD, (pr * H + u) * 4, ho * ld4(a.drop + pr * H + u));
+            st4(a.HP + pr * H + u, ld4(cellv + 4 * tid));
+            float* gt = a.gates + pr * 4 * H + u;
+            st4(gt, ld4(cellv + 512 + 4 * tid)); st4(gt + H, ld4(cellv + 1024 + 4 * tid));
+            st4(gt + 2 * H, ld4(cellv + 1536 + 4 * tid)); st4(gt + 3 * H, ld4(cellv + 2048 + 4 * tid));
+        }
+        __syncthreads();                               // cellv / w_pf are free for the next 32 rows
+    };
+    auto prefetch = [&](int l, int t, int r0, int bt) {
+        if (tid < 4 * WROWS && r0 + (tid >> 2) < bt) {
+            float* dst = w_pf + 256 * wave;
+            const int row = r0 + (tid >> 2), u = 16 * j + 4 * (tid & 3);
+            const float* tp;
+            if (l == 0) {
+                const long long tok = a.tokens[prow(w_off[t], row, rp)];
+                tp = a.table + (tok < 0 ? 0 : (tok < a.V ? tok : a.V - 1)) * H3 + u;
+            } else tp = a.b_ih[l] + u;
+            const float* bp = a.b_hh[l] + u;
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                __builtin_amdgcn_global_load_lds(tp + q * H, PPK_LDS_PTR(dst + q * 512), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds(bp + q * H, PPK_LDS_PTR(dst + (3 + q) * 512), 16, 0, 0);
+            }
+        }
+    };
+    // acc += W . X[rows r0 .. r0 + 31]: both row tiles' operands requested before the first MFMA
+    auto product = [&](f32x4 (&acc)[NR][4], auto& w, const float* X, long long rowbase, int r0, int bt, int nrt, auto kk, auto nsel) {
+        constexpr int KK = decltype(kk)::v, NSEL = decltype(nsel)::v;
+        constexpr int K = 32 * KK;
+        float b0[KK], b1[KK];
+        {
+            const int r = r0 + n < bt ? r0 + n : bt - 1;
+            load_b<KK>(b0, X, (prow(rowbase, r, rp) * K + wave * 4 * KK) * 4, g);
+        }
+        if (nrt > 1) {
+            const int r = r0 + 16 + n < bt ? r0 + 16 + n : bt - 1;
+            load_b<KK>(b1, X, (prow(rowbase, r, rp) * K + wave * 4 * KK) * 4, g);
+        }
+        mma_gates<KK, NSEL>(acc[0], w, b0);
+        if (nrt > 1) mma_gates<KK, NSEL>(acc[1], w, b1);
+    };
+
+    for (int t = 0; t < a.T; ++t) {
+        const int bt = rows_of(a.bs[t], rp);
+        if (bt == 0) break;
+        const long long base = w_off[t], pbase = t > 0 ? w_off[t - 1] : 0;
+        // ---- stack entering this step: the owned rows rho = j + k NWG (k < 8)
+        {
+            const int k = tid >> 6, e = tid & 63, rho = j + k * NWG;
+            // first 2W elements of the previous rows: requested ahead of the wait (this workgroup's own stores)
+            if (rho < bt) {
+                const float* src = t > 0 ? a.S + prow(pbase, rho, rp) * DW : (a.S0 ? a.S0 + prow(0, rho, rp) * DW : nullptr);
+                const int lim = 2 * W < DW ? 2 * W : DW;
+                l_sp[k * 128 + e] = src && e < lim ? src[e] : 0.f;
+                l_sp[k * 128 + 64 + e] = src && e + 64 < lim ? src[e + 64] : 0.f;
+            }
+        }
+        if (!ws_wait(ctr + (L - 1) * CTR_STRIDE, NWG * (t + 1), a.status, &w_flag)) return;
+        {
+            // heads of the owned rows: thread = (row k, group of workgroups grp, 4 columns o4); partials added in workgroup order
+            const int k = tid >> 6, grp = (tid >> 4) & 3, o4 = tid & 15, rho = j + k * NWG;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (rho < bt && 4 * o4 < ldcs) {
+                constexpr int NP = (NWG + 3) / 4;
+                f32x4 p[NP];
+#pragma unroll
+                for (int i = 0; i < NP; ++i) {
+                    const int jj = grp + 4 * i < NWG ? grp + 4 * i : NWG - 1;
+                    p[i] = ld4_sc1(hpart, (((long long)jj * LROWS + rho) * ldcs + 4 * o4) * 4);
+                }
+#pragma unroll
+                for (int i = 0; i < NP; ++i) if (grp + 4 * i < NWG) v += p[i];
+            }
+            st4(w_part + ((grp * LOWN + k) * 64 + 4 * o4), v);
+            __syncthreads();
+            const int o = tid & 63;
+            if (rho < bt) {
+                float s4 = 0.f;
+                if (o < nout) s4 = (((w_part[(0 * LOWN + k) * 64 + o] + w_part[(1 * LOWN + k) * 64 + o]) + w_part[(2 * LOWN + k) * 64 + o]) + w_part[(3 * LOWN + k) * 64 + o]) + a.bcs[o];
+                l_act[k * 64 + o] = s4;
+            }
+            __syncthreads();
+            if (rho < bt) {
+                float* act = l_act + k * 64;
+                if (o == 0) {
+                    const float p0 = act[0], p1 = act[1], p2 = act[2];
+                    const float m = fmaxf(p0, fmaxf(p1, p2));
+                    const float e0 = expf(p0 - m), e1 = expf(p1 - m), e2 = expf(p2 - m);
+                    const float inv = 1.0f / (e0 + e1 + e2);
+                    act[0] = e0 * inv; act[1] = e1 * inv; act[2] = e2 * inv;
+                } else if (o >= 3 && o < nout) act[o] = tanhf(act[o]);
+            }
+            __syncthreads();
+            if (rho < bt) {
+                const float* act = l_act + k * 64;
+                const float* sp = l_sp + k * 128;
+                float tv = 0.f;
+                if (o < W) tv = act[2] * sp[o] + act[0] * act[3 + o] + act[1] * (o + W < DW ? sp[o + W] : 0.f);
+                l_top[k * 64 + o] = tv;
+            }
+            __syncthreads();
+            if (tid < LOWN * 16) {
+                const int k2 = tid >> 4, x4 = tid & 15, rho2 = j + k2 * NWG;
+                if (rho2 < bt && 4 * x4 < KS) st4_sc1(a.XS, (prow(base, rho2, rp) * KS + 4 * x4) * 4, ld4(l_top + k2 * 64 + 4 * x4));
+            }
+        }
+        group_signal(ctr + L * CTR_STRIDE);
+        {
+            // behind the signal: the whole rows (one wave per owned row), S and CS for the backward
+            const int k = wave, rho = j + k * NWG;
+            if (rho < bt) {
+                const float* act = l_act + k * 64;
+                const float a_push = act[0], a_pop = act[1], a_noop = act[2];
+                const float* sp = t > 0 ? a.S + prow(pbase, rho, rp) * DW : (a.S0 ? a.S0 + prow(0, rho, rp) * DW : nullptr);
+                float* sn = a.S + prow(base, rho, rp) * DW;
+                for (int e0 = 0; e0 < DW; e0 += 64 * 8) {
+                    float c[8], u[8], d[8];
+#pragma unroll
+                    for (int x = 0; x < 8; ++x) {
+                        const int e = e0 + 64 * x + lane;
+                        c[x] = sp && e < DW ? sp[e] : 0.f;
+                        u[x] = e < W ? act[3 + (e < W ? e : 0)] : (sp && e < DW ? sp[e - W] : 0.f);
+                        d[x] = sp && e + W < DW ? sp[e + W] : 0.f;
+                    }
+#pragma unroll
+                    for (int x = 0; x < 8; ++x) {
+                        const int e = e0 + 64 * x + lane;
+                        if (e < DW) sn[e] = a_noop * c[x] + a_push * u[x] + a_pop * d[x];
+                    }
+                }
+                if (lane < nout) a.CS[prow(base, rho, rp) * ldcs + lane] = act[lane];
+            }
+        }
+        // ---- layers
+#pragma unroll
+        for (int l = 0; l < L; ++l) {
+            if (!ws_wait(ctr + (l == 0 ? L : l - 1) * CTR_STRIDE, NWG * (t + 1), a.status, &w_flag)) return;
+            for (int r0 = 0; r0 < bt; r0 += 32) {
+                const int nrt = bt - r0 > 16 ? 2 : 1;
+                prefetch(l, t, r0, bt);
+                f32x4 acc[NR][4];
+#pragma unroll
+                for (int rt = 0; rt < NR; ++rt)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) acc[rt][q] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (t > 0) product(acc, wh[l], a.Hs + (long long)l * a.NT * H, pbase, r0, bt, nrt, IntK<KH>{}, IntK<3>{});
+                else product(acc, wh[l], a.h0 + (long long)l * a.B * H, 0, r0, bt, nrt, IntK<KH>{}, IntK<3>{});
+                if (l == 0) product(acc, wi0, a.XS, base, r0, bt, nrt, IntK<KX>{}, IntK<2>{});
+                else product(acc, wi[l > 0 ? l - 1 : 0], (a.drop ? a.HD : a.Hs) + (long long)(l - 1) * a.NT * H, base, r0, bt, nrt, IntK<KH>{}, IntK<2>{});
+                epilogue(acc, l, t, r0, bt, nrt);
+                if (l == L - 1) heads_pair(l, r0, bt);
+            }
+            group_signal(ctr + l * CTR_STRIDE);
+        }
+    }
 }
 
 // [3+W, H] -> [H, ldcs] (zero padded)
@@ -1057,6 +1320,27 @@ template <int H, int KS> WsKernel pick_l(int L, int nr)
     if (L == 2) return nr == 1 ? k_seq_fwd_ws<H, KS, 2, 1> : k_seq_fwd_ws<H, KS, 2, 2>;
     return nullptr;
 }
+template <int H, int KS> WsKernel pick_ll(int L)
+{
+    if (L == 1) return k_seq_fwd_wsl<H, KS, 1>;
+    if (L == 2) return k_seq_fwd_wsl<H, KS, 2>;
+    return nullptr;
+}
+WsKernel pick_fwdl(int H, int ks, int L)
+{
+    if (ks == 64) {
+        if (H == 512) return pick_ll<512, 64>(L);
+        if (H == 256) return pick_ll<256, 64>(L);
+        if (H == 128) return pick_ll<128, 64>(L);
+        if (H == 64) return pick_ll<64, 64>(L);
+        if (H == 32) return pick_ll<32, 64>(L);
+    } else if (ks == 32) {
+        if (H == 128) return pick_ll<128, 32>(L);
+        if (H == 64) return pick_ll<64, 32>(L);
+        if (H == 32) return pick_ll<32, 32>(L);
+    }
+    return nullptr;
+}
 // nr: 16-row tiles of the batch (1: at most 16 sequences, 2: at most 32)
 WsKernel pick_fwd(int H, int ks, int L, int nr)
 {
@@ -1099,6 +1383,21 @@ bool ws_plan(int64_t B, int64_t H, int& R, int& nr)
     return true;
 }
 
+// replicas of the looped forward: every CU gets a workgroup; rows of a replica <= 256 and <= 8 x H / 16 (stack ownership)
+bool wsl_plan(int64_t B, int64_t H, int& R);
+bool wsl_plan_ok(int64_t B, int64_t H) { int R; return wsl_plan(B, H, R); }
+bool wsl_plan(int64_t B, int64_t H, int& R)
+{
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return false;
+    const int64_t nwg = H / 16, rmax = cus / nwg;
+    if (B < 1 || rmax < 1) return false;
+    const int64_t r = std::min<int64_t>((B + 31) / 32, rmax), rows = (B + r - 1) / r;
+    if (rows > LROWS || rows > LOWN * nwg) return false;
+    R = (int)r;
+    return true;
+}
+
 }  // namespace
 
 namespace ppk {
@@ -1123,9 +1422,10 @@ size_t seq_fwd_ws_ws_bytes(int64_t B, int64_t H, int64_t L, int64_t W)
 bool seq_fwd_ws_ok(int64_t T, int64_t B, int64_t NT, int64_t H, int64_t L, int64_t W, int64_t D, int64_t ks, int64_t ldcs)
 {
     const int mode = seq_persist_mode(-2);
-    if (mode != 2 && mode != -1) return false;
+    if (mode != 2 && mode != 3 && mode != -1) return false;
     if (T < 1 || T > MAXT || B < 1 || L < 1 || L > WS_MAXL || H % 16 || L * NT * 4 * H * 4 >= (1LL << 31)) return false;      // byte offsets of the buffer accesses
     if (ldcs != (3 + W + 31) / 32 * 32 || ks != (W + 31) / 32 * 32 || ldcs > 64) return false;
+    if (mode == 3 && B > WROWS && wsl_plan_ok(B, H)) return false;      // mode 3: the looped forward takes the batches beyond one 32-row replica
     int R, nr;
     if (!ws_plan(B, H, R, nr)) return false;            // every workgroup resident at once, one per CU
     if (mode == -1 && !seq_auto_ws(B, H, R)) return false;
@@ -1190,7 +1490,7 @@ size_t seq_bwd_ws_ws_bytes(int64_t B, int64_t H, int64_t L, int64_t W)
 bool seq_bwd_ws_ok(int64_t T, int64_t B, int64_t NT, int64_t H, int64_t L, int64_t W, int64_t D, int64_t ks, int64_t ldcs)
 {
     const int mode = seq_persist_mode(-2);
-    if (mode != 2 && mode != -1) return false;
+    if (mode != 2 && mode != 3 && mode != -1) return false;
     if (T < 1 || T > MAXT || B < 1 || L < 1 || L > WS_MAXL || H % 16) return false;
     if (ldcs != (3 + W + 31) / 32 * 32 || ks != (W + 31) / 32 * 32 || ldcs > 64) return false;
     if (NT * 3 * H * 4 * L >= (1LL << 31)) return false;              // byte offsets of the buffer accesses into DGI / DGH
@@ -1240,6 +1540,74 @@ int seq_bwd_ws(int64_t T, const int64_t* bs, int64_t B, int64_t NT, int64_t H, i
     }
     float* ptrs[5] = {dXS, DGI, DGH, DCS, dh0};
     const long long counts[5] = {NT * ks, (long long)L * NT * 3 * H, (long long)L * NT * 3 * H, NT * ldcs, (long long)L * B * H};
+    return seq_poison(a.status, ptrs, counts, 5, stream);
+}
+
+// ---- looped forward (mode 3: beyond the batches one launch of <= 32-row replicas holds) ----------------------------------
+size_t seq_fwd_wsl_ws_bytes(int64_t B, int64_t H, int64_t L, int64_t W)
+{
+    int R = 1;
+    if (H % 16 || L > WS_MAXL || !wsl_plan(B, H, R)) return 0;
+    const int64_t ldcs = (3 + W + 31) / 32 * 32, nwg = H / 16;
+    return ppk_align_up(sizeof(float) * (size_t)H * (size_t)ldcs, 256) + ppk_align_up(sizeof(int) * ((size_t)R * (size_t)(L + 1) * CTR_STRIDE + 64), 256)
+           + ppk_align_up(sizeof(float) * (size_t)R * (size_t)nwg * LROWS * (size_t)ldcs, 256);
+}
+
+bool seq_fwd_wsl_ok(int64_t T, int64_t B, int64_t NT, int64_t H, int64_t L, int64_t W, int64_t D, int64_t ks, int64_t ldcs)
+{
+    const int mode = seq_persist_mode(-2);
+    if ((mode != 3 && mode != -1) || B <= WROWS) return false;
+    if (T < 1 || T > MAXT || L < 1 || L > WS_MAXL || H % 16 || L * NT * 4 * H * 4 >= (1LL << 31)) return false;
+    if (ldcs != (3 + W + 31) / 32 * 32 || ks != (W + 31) / 32 * 32 || ldcs > 64 || 2 * W > 128) return false;
+    int R;
+    if (!wsl_plan(B, H, R)) return false;
+    // auto: where it was measured faster than both other schedules — rows per replica x H <= 64 x 512 (H 512: batch 257 .. 512,
+    // training step 0.91 - 0.92 of the faster other one; 0.98 at 768, 1.03 at 1024, 1.12 at 2048.  H 256: batch 513 .. 1536,
+    // 0.90 - 0.92.  H 128: up to 2048, 0.69 - 1.0: profiles/r03_ws_replicas.txt)
+    if (mode == -1 && (B + R - 1) / R * H > 64 * 512) return false;
+    (void)D;
+    return pick_fwdl((int)H, (int)ks, (int)L) != nullptr;
+}
+
+int seq_fwd_wsl(int64_t T, const int64_t* bs, int64_t B, int64_t NT, int64_t V, int64_t H, int64_t L, int64_t W, int64_t D,
+                const int64_t* tokens, const float* table, const float* wx0s, int64_t ks,
+                const float* const* w_ih, const float* const* w_hh, const float* const* b_ih, const float* const* b_hh,
+                const float* wcs, const float* bcs, const float* h0, const float* S0,
+                float* XS, float* Hs, float* HP, float* gates, float* S, float* CS, int64_t ldcs,
+                const float* drop, float* Hdrop, void* ws, size_t ws_bytes, hipStream_t stream)
+{
+    if (ws_bytes < seq_fwd_wsl_ws_bytes(B, H, L, W)) PPK_FAIL(PPK_ERR_WS, "seq_fwd_wsl: workspace too small");
+    int R = 1;
+    if (!wsl_plan(B, H, R)) PPK_FAIL(PPK_ERR_UNSUP, "seq_fwd_wsl: the batch does not fit one launch");
+    WsKernel kern = pick_fwdl((int)H, (int)ks, (int)L);
+    if (!kern) PPK_FAIL(PPK_ERR_UNSUP, "seq_fwd_wsl: unsupported shape");
+    WsArgs a{};
+    a.T = (int)T; a.B = (int)B; a.W = (int)W; a.D = (int)D; a.V = (int)V; a.ldcs = (int)ldcs; a.DW = (int)(D * W); a.R = R;
+    a.NT = NT;
+    a.tokens = tokens; a.table = table; a.wx0s = wx0s;
+    for (int l = 0; l < (int)L; ++l) { a.w_ih[l] = w_ih[l]; a.w_hh[l] = w_hh[l]; a.b_ih[l] = b_ih[l]; a.b_hh[l] = b_hh[l]; }
+    a.bcs = bcs; a.h0 = h0; a.S0 = S0;
+    a.XS = XS; a.Hs = Hs; a.HP = HP; a.gates = gates; a.S = S; a.CS = CS;
+    a.drop = L > 1 ? drop : nullptr; a.HD = Hdrop;
+    for (int t = 0; t < (int)T; ++t) a.bs[t] = (int)bs[t];
+    const int nwg = (int)(H / 16);
+    char* cur = (char*)ws;
+    float* wcs_t = (float*)ppk_carve(cur, sizeof(float) * (size_t)H * (size_t)ldcs);
+    const size_t nctr = (size_t)R * (size_t)(L + 1) * CTR_STRIDE + 64;
+    int* ctr = (int*)ppk_carve(cur, sizeof(int) * nctr);
+    a.wcs_t = wcs_t; a.ctr = ctr; a.status = ctr + (size_t)R * (size_t)(L + 1) * CTR_STRIDE;
+    a.hpart = (float*)ppk_carve(cur, sizeof(float) * (size_t)R * (size_t)nwg * LROWS * (size_t)ldcs);
+    PPK_HIP(hipMemsetAsync(ctr, 0, sizeof(int) * nctr, stream));
+    k_ws_wcs_transpose<<<dim3((unsigned)std::min<int64_t>((H * ldcs + 255) / 256, 1024)), dim3(256), 0, stream>>>(wcs, (int)(3 + W), (int)H, (int)ldcs, wcs_t);
+    PPK_CHECK_LAUNCH("k_ws_wcs_transpose");
+    {
+        const double flops = 2.0 * (double)NT * 3.0 * (double)H * ((double)ks + (2.0 * (double)L - 1.0) * (double)H);
+        ProfScope prof(PK_SEQ_FWD, flops, stream);
+        kern<<<dim3((unsigned)(R * nwg)), dim3(NTH), 0, stream>>>(a);
+        PPK_CHECK_LAUNCH("k_seq_fwd_wsl");
+    }
+    float* ptrs[5] = {Hs, CS, XS, S, a.drop ? Hdrop : nullptr};
+    const long long counts[5] = {(long long)L * NT * H, NT * ldcs, NT * ks, NT * D * W, (long long)(L - 1) * NT * H};
     return seq_poison(a.status, ptrs, counts, 5, stream);
 }
 

@@ -221,7 +221,7 @@ size_t ppk_stackgru_seq_fwd_workspace_bytes(int64_t B, int64_t H, int64_t L, int
     if (B < 1 || H < 1 || L < 1 || W < 1) return 0;
     const int64_t ldcs = (3 + W + 31) / 32 * 32;
     return (size_t)L * ppk_align_up(sizeof(float) * (size_t)B * 3 * (size_t)H, 256) + ppk_align_up(sizeof(float) * (size_t)B * (size_t)ldcs, 256)
-           + std::max(ppk::seq_fwd_persist_ws_bytes(B, H, L, W), ppk::seq_fwd_ws_ws_bytes(B, H, L, W));
+           + std::max(std::max(ppk::seq_fwd_persist_ws_bytes(B, H, L, W), ppk::seq_fwd_ws_ws_bytes(B, H, L, W)), ppk::seq_fwd_wsl_ws_bytes(B, H, L, W));
 }
 
 // table [V, 3H]  = emb . W_ih0[:, :E]^T + b_ih0      (embedding half of the layer-0 input product)
@@ -251,6 +251,9 @@ int ppk_stackgru_seq_fwd(int64_t T, const int64_t* batch_sizes_host, int64_t B, 
     if (ppk::seq_fwd_ws_ok(T, B, NT, H, L, W, D, ks, ldcs))
         return ppk::seq_fwd_ws(T, batch_sizes_host, B, NT, V, H, L, W, D, tokens, table, wx0s, ks, w_ih, w_hh, b_ih, b_hh,
                                wcs, bcs, h0, S0, XS, Hs, HP, gates, S, CS, ldcs, drop, Hdrop, workspace, ws_bytes, stream);
+    if (ppk::seq_fwd_wsl_ok(T, B, NT, H, L, W, D, ks, ldcs))
+        return ppk::seq_fwd_wsl(T, batch_sizes_host, B, NT, V, H, L, W, D, tokens, table, wx0s, ks, w_ih, w_hh, b_ih, b_hh,
+                                wcs, bcs, h0, S0, XS, Hs, HP, gates, S, CS, ldcs, drop, Hdrop, workspace, ws_bytes, stream);
     // the whole time loop as one persistent launch (ppk_seq_persist.hip) when the shape allows it
     if (ppk::seq_fwd_persist_ok(T, B, NT, H, L, W, D, ks, ldcs))
         return ppk::seq_fwd_persist(T, batch_sizes_host, B, NT, V, H, L, W, D, tokens, table, wx0s, ks, w_ih, w_hh, b_ih, b_hh,

@@ -153,28 +153,32 @@ def _seq_kernels_launched(H, B, T=6, mode=-1, W=10):
     return {lib.ppk_prof_kind_name(k).decode() for k in range(nk) if launches[k]}
 
 
-@pytest.mark.parametrize('H,B,persistent', [
-    (512, 1024, True), (512, 2048, True), (512, 512, False), (128, 2048, False), (256, 2048, False), (256, 4096, True),
-    (384, 1024, True), (768, 512, True), (768, 2048, False), (1024, 512, True),
+@pytest.mark.parametrize('H,B,fwd_single,bwd_single', [
+    (512, 1024, True, True), (512, 2048, True, True), (512, 512, False, False), (256, 2048, False, False), (256, 4096, True, True),
+    (384, 1024, True, True), (768, 512, True, True), (768, 2048, False, False), (1024, 512, True, True),
+    (128, 2048, True, False),      # H 128 never fills the machine with row-block groups; its forward takes the looped weights-stationary kernel
 ])
-def test_auto_mode_picks_the_measured_faster_schedule(H, B, persistent):
+def test_auto_mode_picks_the_measured_faster_schedule(H, B, fwd_single, bwd_single):
     """ppk_seq_persist_mode(-1): the rule of seq_auto_persistent over batch AND hidden size (a group is H / 32 workgroups;
-    profiles/r03_persist_shapes.txt has the timings of both schedules at these shapes)."""
+    profiles/r03_persist_shapes.txt has the timings of both schedules at these shapes).  The helper's 10 stack columns have no
+    weights-stationary instantiation at H >= 256, so those shapes show the row-block rule alone."""
     kinds = _seq_kernels_launched(H, B)
-    assert ('k_seq_fwd' in kinds) == persistent, (H, B, sorted(kinds))
-    assert ('k_seq_bwd' in kinds) == persistent, (H, B, sorted(kinds))
+    assert ('k_seq_fwd' in kinds) == fwd_single, (H, B, sorted(kinds))
+    assert ('k_seq_bwd' in kinds) == bwd_single, (H, B, sorted(kinds))
 
 
-@pytest.mark.parametrize('H,B,mode,single_launch', [
-    (512, 16, -1, True), (512, 32, -1, True), (512, 33, -1, True), (512, 256, -1, True), (512, 288, -1, False), (512, 16, 0, False), (512, 7, 2, True),
-    (256, 21, -1, True), (256, 500, -1, True), (128, 9, 2, True), (96, 9, 2, False),
+@pytest.mark.parametrize('H,B,mode,fwd_single,bwd_single', [
+    (512, 16, -1, True, True), (512, 32, -1, True, True), (512, 33, -1, True, True), (512, 256, -1, True, True), (512, 400, -1, True, False),
+    (512, 600, -1, False, False), (512, 16, 0, False, False), (512, 7, 2, True, True), (512, 400, 2, False, False), (512, 700, 3, True, False),
+    (256, 21, -1, True, True), (256, 500, -1, True, True), (128, 9, 2, True, True), (96, 9, 2, False, False),
 ])
-def test_small_batches_take_the_weights_stationary_kernels(H, B, mode, single_launch):
+def test_small_batches_take_the_weights_stationary_kernels(H, B, mode, fwd_single, bwd_single):
     """Where one launch of replicas (<= 32 sequences each, H / 16 workgroups each, one workgroup per CU) fits the device the
     whole time loop is ONE launch per pass with the weights resident in registers (ppk_seq_ws.hip; reported under the
-    k_seq_fwd / k_seq_bwd profiling kinds) in auto mode and mode 2: H 512 up to 256 sequences, H 256 up to 512; beyond that,
-    in mode 0 and at hidden sizes without an instantiation the per-step launches run."""
+    k_seq_fwd / k_seq_bwd profiling kinds) in auto mode and mode 2: H 512 up to 256 sequences, H 256 up to 512.  Beyond that the
+    forward alone has a looped variant (replicas of up to 256 rows): auto takes it up to 64 rows per replica (H 512: batch 512),
+    mode 3 wherever it fits.  In mode 0 and at hidden sizes without an instantiation the per-step launches run."""
     kinds = _seq_kernels_launched(H, B, mode=mode, W=10 if H <= 128 else 40)      # H >= 256 is instantiated for 64 stack columns only
-    assert ('k_seq_fwd' in kinds) == single_launch, (H, B, sorted(kinds))
-    assert ('k_seq_bwd' in kinds) == single_launch, (H, B, sorted(kinds))
-    assert ('k_stack_fwd' in kinds) != single_launch, (H, B, sorted(kinds))
+    assert ('k_seq_fwd' in kinds) == fwd_single, (H, B, sorted(kinds))
+    assert ('k_seq_bwd' in kinds) == bwd_single, (H, B, sorted(kinds))
+    assert ('k_stack_fwd' in kinds) != fwd_single, (H, B, sorted(kinds))

@@ -51,7 +51,7 @@ def run(mode, reps=10):
 
 
 base, dt0, k0 = run(0)
-for mode in (1, 2):
+for mode in (1, 2, 3):
     outs, dt, kinds = run(mode)
     worst = max(float((a - b).abs().max() / (b.abs().max() + 1e-30)) for a, b in zip(outs, base))
     print(f'mode {mode}: fwd+bwd {dt:.3f} ms (per-step launches {dt0:.3f} ms), worst rel-to-max difference vs mode 0 {worst:.2e}')

@@ -1,6 +1,6 @@
 """Training step (encode, decode, graph loss, backward) against batch size for the per-step launches (mode 0), the
 row-block persistent kernels (mode 1) and the weights-stationary kernels with replicas (mode 2): where auto mode should
-hand over.  Usage: python tools/ws_replica_shapes.py [H=512]"""
+hand over.  Usage: python tools/ws_replica_shapes.py [H=512] [bundles of 16, comma separated]"""
 import os
 import sys
 
@@ -19,7 +19,7 @@ torch.manual_seed(0)
 model = Encoder(params, None, None, batch_size=1, batch_mode='Packed')
 model.gru_vae.train()
 print(f'# H {H}: ms per training step; bundles of 16 SMILES of 20..100 tokens')
-for nb in [1, 2, 3, 4, 6, 8, 12, 16, 24, 32]:
+for nb in ([1, 2, 3, 4, 6, 8, 12, 16, 24, 32] if len(sys.argv) < 3 else [int(x) for x in sys.argv[2].split(',')]):
     rng = np.random.default_rng(nb)
     seqs, gs, sizes = bench.synth_batch(rng, nb, 16)
     enc, dec, tgt, g_flat = bench.to_device_batch(seqs, gs, 'cuda')
@@ -27,7 +27,7 @@ for nb in [1, 2, 3, 4, 6, 8, 12, 16, 24, 32]:
     model.update_batch_size(B)
     eps = torch.randn(B, params['latent_dim'], device='cuda')
     out = []
-    for mode in (0, 1, 2):
+    for mode in (0, 1, 2, 3):
         _C.lib.ppk_seq_persist_mode(mode)
 
         def step():
@@ -45,5 +45,5 @@ for nb in [1, 2, 3, 4, 6, 8, 12, 16, 24, 32]:
         e1.record()
         torch.cuda.synchronize()
         out.append(e0.elapsed_time(e1) / 5)
-    print(f'B {B:5d}: per-step launches {out[0]:8.3f}, row-block persistent {out[1]:8.3f}, weights-stationary {out[2]:8.3f}   ws / best other {out[2] / min(out[0], out[1]):.3f}')
+    print(f'B {B:5d}: per-step launches {out[0]:8.3f}, row-block persistent {out[1]:8.3f}, weights-stationary {out[2]:8.3f} (looped forward beyond 32 rows: {out[3]:8.3f})   ws / best other {out[2] / min(out[0], out[1]):.3f}')
 _C.lib.ppk_seq_persist_mode(-1)

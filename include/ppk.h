@@ -172,7 +172,10 @@ int64_t ppk_nt_small_grid_limit(int64_t limit);
  *    1  row-block persistent at ANY batch, wherever the shape is supported (H % 32 == 0, ks / ldcs at their minimal paddings
  *       roundup32(W) / roundup32(3 + W), one group's workgroups resident together on the current device); an
  *       unsupported shape takes the per-step launches.  Never the weights-stationary kernels;
- *    2  like auto (the value the tests use to say "the weights-stationary kernels where they exist").
+ *    2  the weights-stationary kernels wherever one launch of <= 32-row replicas fits (never the looped forward), auto's choice elsewhere;
+ *    3  like 2, and the looped weights-stationary forward (replicas of up to 256 rows; forward only) for every larger batch it fits —
+ *       auto takes that forward only where it was measured faster (rows per replica x H <= 32768: H 512 batch 257 - 512, H 256 batch
+ *       513 - 1536); at batch 2048 / H 512 it is slower than the row-block kernel (profiles/r03_ws_replicas.txt).
  * Weights-stationary shapes: ceil(B / 16) replicas (fewer, of up to 32 rows, when replicas x H / 16 would exceed the CUs), L <= 2, H in {32, 64, 128, 256, 512} with ks == ldcs-minimal paddings, ldcs <= 64
  * (H >= 256: ks == 64 only), the owned rows' stacks within the workgroup's LDS (32 / (H / 16) rows x D x W floats: 2 images
  * forward, 3 backward).  fp32 operands whatever ppk_mfma_mode says.  Measured (MI355X, H 512, L 2,

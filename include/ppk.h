@@ -176,10 +176,10 @@ int64_t ppk_nt_small_grid_limit(int64_t limit);
  *    3  like 2, and the looped weights-stationary forward (replicas of up to 256 rows; forward only) for every larger batch it fits —
  *       auto takes that forward only where it was measured faster (rows per replica x H <= 32768: H 512 batch 257 - 512, H 256 batch
  *       513 - 1536); at batch 2048 / H 512 it is slower than the row-block kernel (profiles/r03_ws_replicas.txt).
- * Weights-stationary shapes: ceil(B / 16) replicas (fewer, of up to 32 rows, when replicas x H / 16 would exceed the CUs), L <= 2, H in {32, 64, 128, 256, 512} with ks == ldcs-minimal paddings, ldcs <= 64
+ * Weights-stationary shapes: ceil(B / 16) replicas (fewer, of up to 32 rows, when replicas x H / 16 would exceed the CUs), L <= 2 (3 at H <= 256), H in {32, 64, 128, 256, 512} with ks == ldcs-minimal paddings, ldcs <= 64
  * (H >= 256: ks == 64 only), the owned rows' stacks within the workgroup's LDS (32 / (H / 16) rows x D x W floats: 2 images
  * forward, 3 backward).  fp32 operands whatever ppk_mfma_mode says.  Measured (MI355X, H 512, L 2,
- * bundles of 6 - 21 sequences of 20 - 100 tokens, whole training step): 15.5 ms -> 8.1 ms (profiles/r03_small_batch_ws.txt); batch 64: 17.2 -> 9.0 ms, 256: 19.9 -> 12.9 ms
+ * bundles of 6 - 21 sequences of 20 - 100 tokens, whole training step): 15.7 ms -> 8.0 ms (profiles/r03_small_batch_ws.txt); batch 64: 17.2 -> 9.0 ms, 256: 19.9 -> 12.9 ms
  * (profiles/r03_ws_replicas.txt).
  * Any other value only queries.  Process-global like ppk_nt_small_grid_limit.  Returns the value in force.
  * A persistent launch (either kind) whose workgroups lose a hand-off (bounded wait, ~3 s; another process holding the GPU can cause

@@ -1,27 +1,30 @@
-// K1 forward for SMALL batches (<= 32 sequences: the reference's own regime, one bundle of <= 21 SMILES per optimizer
-// step, experiments/chem_reactions/reactions_vae.py:52-59) as ONE persistent launch with the weights STATIONARY IN
-// REGISTERS (paccmann_chemistry StackGRU reached from paccmann_polymer/models/paccmann_encoder.py:166,168; semantics
-// SURVEY.md Appendix B).
+// K1 for SMALL AND MEDIUM batches — first of all the reference's own regime, one bundle of <= 21 SMILES per optimizer
+// step (experiments/chem_reactions/reactions_vae.py:52-59) — as ONE persistent launch per pass with the weights STATIONARY
+// IN REGISTERS (paccmann_chemistry StackGRU reached from paccmann_polymer/models/paccmann_encoder.py:166,168; semantics
+// SURVEY.md Appendix B).  Forward (k_seq_fwd_ws), backward (k_seq_bwd_ws), and a looped forward for larger batches
+// (k_seq_fwd_wsl).
 //
-// With <= 32 rows the per-step launches and the row-block persistent kernel (ppk_seq_persist.hip) both spend a timestep
+// With few rows the per-step launches and the row-block persistent kernel (ppk_seq_persist.hip) both spend a timestep
 // streaming every weight (9.8 MB at H 512, L 2) past one or two 32-row tiles: ~35 us per timestep on 16 CUs.  Here the
 // hidden units are dealt 16 to a workgroup (H / 16 workgroups of 512 threads, one per CU) and a workgroup keeps ITS gate
 // rows of every matrix — r, z, n of its 16 units: 48 x (ks + (2L-1) H) floats = 307 KB at H 512, L 2 — in the VGPRs of its
 // eight waves for the whole launch (150 registers per lane), as A operands of v_mfma_f32_16x16x4_f32:
 //     D[unit][row] += W[unit][k] . x[row][k]       (M = 16 gate rows, N = 16 batch rows, K = 4)
-// The eight waves split K; a lane's B operands are 16 consecutive floats of one activation row, loaded straight from
-// global memory into registers (no LDS staging: the activations are 2 KB per row).  Only activations move: per timestep
-// a workgroup reads the rows' stack tops and hidden states (<= 32 x 4.4 KB) and writes its 16 units of them.
+// The eight waves split K; a lane's B operands are 16 floats of one activation row, loaded straight from global memory
+// into registers (no LDS staging: the activations are 2 KB per row).  Only activations move: per timestep a workgroup
+// reads the rows' stack tops and hidden states (<= 32 x 4.4 KB) and writes its 16 units of them.
 // The eight K-chunk partial tiles are summed in wave order through LDS (fixed order: bitwise reproducible), the GRU
 // cell runs on the sums, and the stack heads are split over the workgroups as in ppk_seq_persist.hip (every workgroup
 // multiplies its 16 units with its slice of [W_c; W_s], the row's owner adds the partials in workgroup order).  The
 // owner of a row keeps that row's stack in LDS for the whole launch (global S is write-only here).
+// A batch of more than 16 sequences is dealt round-robin to independent REPLICAS of <= 16 (32) rows, each with its own
+// H / 16 workgroups, counters and partial buffers (struct Rep): one launch while replicas x H / 16 <= CUs.
 //
-// Order inside a timestep (L >= 2):  W_hh0 h_0(t-1)  |wait heads| stack update of the owned rows |signal x|
+// Order inside a timestep (L >= 2):  W_hh0 h_0(t-1)  |wait heads| stack top of the owned rows |signal x| rest of the rows
 //   |wait x| W_ih0 x(t), cell 0 |signal h_0|  W_hh1 h_1(t-1)  |wait h_0| W_ih1 h_0(t), cell 1, heads partial |signal h_1, heads|
-// — the products that need nothing new sit in front of the waits.  Three hand-offs per timestep, the protocol of
-// ppk_seq_common.h (sc1 write-through stores, every wave drains, barrier, one agent-scope add; one lane polls, acquire,
-// barrier, sc1 loads to registers).
+// — the products that need nothing new sit in front of the waits, what only later kernels read is stored behind the
+// signals.  Three hand-offs per timestep: sc1 write-through stores, every wave drains, barrier, one agent-scope add; one
+// lane polls (sc1), barrier, sc1 loads to registers (ws_wait below: why no acquire).
 #include "ppk_common.h"
 #include "ppk_kernels.h"
 #include "ppk_seq_common.h"
@@ -36,7 +39,7 @@ constexpr int MAXT = ppk::SEQP_MAXT;
 constexpr int NTH = 512;                       // 8 waves: two per SIMD, 256 registers each
 constexpr int WROWS = 32;                      // batch rows of a launch (two 16-row MFMA tiles)
 constexpr int STACK_FLOATS = 12288;            // LDS for the owned rows' stacks (two images per row)
-constexpr int WS_MAXL = 2;
+constexpr int WS_MAXL = 3;                      // three layers: H <= 256 (the weight registers: 3 (ks + (2L-1) H) / 32 per lane)
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
@@ -1295,6 +1298,7 @@ template <int H, int KS> WsBwdKernel pick_bl(int L, int nr)
 {
     if (L == 1) return nr == 1 ? k_seq_bwd_ws<H, KS, 1, 1> : k_seq_bwd_ws<H, KS, 1, 2>;
     if (L == 2) return nr == 1 ? k_seq_bwd_ws<H, KS, 2, 1> : k_seq_bwd_ws<H, KS, 2, 2>;
+    if constexpr (H <= 256) { if (L == 3) return nr == 1 ? k_seq_bwd_ws<H, KS, 3, 1> : k_seq_bwd_ws<H, KS, 3, 2>; }
     return nullptr;
 }
 WsBwdKernel pick_bwd(int H, int ks, int L, int nr)
@@ -1318,12 +1322,14 @@ template <int H, int KS> WsKernel pick_l(int L, int nr)
 {
     if (L == 1) return nr == 1 ? k_seq_fwd_ws<H, KS, 1, 1> : k_seq_fwd_ws<H, KS, 1, 2>;
     if (L == 2) return nr == 1 ? k_seq_fwd_ws<H, KS, 2, 1> : k_seq_fwd_ws<H, KS, 2, 2>;
+    if constexpr (H <= 256) { if (L == 3) return nr == 1 ? k_seq_fwd_ws<H, KS, 3, 1> : k_seq_fwd_ws<H, KS, 3, 2>; }
     return nullptr;
 }
 template <int H, int KS> WsKernel pick_ll(int L)
 {
     if (L == 1) return k_seq_fwd_wsl<H, KS, 1>;
     if (L == 2) return k_seq_fwd_wsl<H, KS, 2>;
+    if constexpr (H <= 256) { if (L == 3) return k_seq_fwd_wsl<H, KS, 3>; }
     return nullptr;
 }
 WsKernel pick_fwdl(int H, int ks, int L)

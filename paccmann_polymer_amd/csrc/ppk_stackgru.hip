@@ -16,7 +16,9 @@
 //   gates [L, NT, 4H] r, z, n, (W_hn h + b_hn)
 //   S     [NT, D, W]  stack after the step           CS [NT, ldcs] softmax(3) | tanh(W)
 //   XS    [NT, ks]    stack top fed to layer 0 (ks = W rounded up to 32, zero padded)
-// Two launch schedules behind the same entry points (ppk_seq_persist_mode):
+// Three launch schedules behind the same entry points (ppk_seq_persist_mode):
+//  * weights-stationary (ppk_seq_ws.hip): small and medium batches, replicas of <= 32 rows whose workgroups keep their rows of
+//    every weight matrix in registers — taken in auto mode wherever one launch fits the device;
 //  * persistent (ppk_seq_persist.hip / ppk_seq_persist_bwd.hip): the whole time loop in ONE launch per pass,
 //    row-block groups synchronised among their own workgroups only — taken in auto mode where the groups fill the
 //    machine (H 512: from batch 1024 up; ppk::seq_auto_persistent);
